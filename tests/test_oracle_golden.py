@@ -1,0 +1,98 @@
+"""The oracle against the vectors produced by the reference's own code (tools/gen_golden*.py).
+CPU only.  This is what pins the oracle."""
+import numpy as np
+
+from conftest import dense_heads, load_golden
+from oracle import align, match
+from oracle import postprocess as pp
+
+
+def test_decode_helpers_bit_exact():
+    g = load_golden("decode.npz")
+    assert np.array_equal(pp.distance2bbox(g["points"], g["dist"]), g["bbox"])
+    assert np.array_equal(pp.distance2kps(g["points"], g["kdist"]), g["kps"])
+
+
+def test_anchor_centers_order():
+    g = load_golden("forward.npz")
+    for s in (8, 16, 32):
+        c = pp.anchor_centers(640 // s, 640 // s, s)
+        assert c.dtype == np.float32 and np.array_equal(c, g[f"centers_s{s}"])
+    assert pp.anchor_centers(80, 80, 8)[:5].tolist() == [[0, 0], [0, 0], [8, 0], [8, 0], [16, 0]]
+
+
+def test_forward_decode_bit_exact():
+    g = load_golden("forward.npz")
+    for ci in range(int(g["n_cases"])):
+        p = f"c{ci}_"
+        outs = dense_heads(g[p + "pos"], g[p + "pos_score"], g[p + "pos_bbox"], g[p + "pos_kps"])
+        s, b, k = pp.decode_heads(outs, (640, 640), float(g[p + "thr"]))
+        for lv in range(3):
+            assert np.array_equal(s[lv], g[p + f"scores{lv}"])
+            assert np.array_equal(b[lv], g[p + f"bboxes{lv}"])
+            assert np.array_equal(k[lv], g[p + f"kpss{lv}"])
+
+
+def test_detect_bit_exact():
+    g = load_golden("detect.npz")
+    n = int(g["n_cases"])
+    assert n == 64
+    seen_empty = False
+    for ci in range(n):
+        p = f"c{ci}_"
+        outs = dense_heads(g[p + "pos"], g[p + "pos_score"], g[p + "pos_bbox"], g[p + "pos_kps"])
+        det, kps = pp.detect_from_heads(outs, tuple(g[p + "shape"]), max_num=int(g[p + "max_num"]),
+                                        metric="max" if int(g[p + "metric"]) == 0 else "default")
+        assert det.shape == g[p + "det"].shape and kps.shape == g[p + "kps"].shape
+        assert det.dtype == np.float32 and kps.dtype == np.float32
+        assert np.array_equal(det, g[p + "det"]), ci
+        assert np.array_equal(kps, g[p + "kps"]), ci
+        seen_empty |= det.shape == (0, 5) and kps.shape == (0, 5, 2)
+    assert seen_empty
+
+
+def test_nms_bit_exact():
+    g = load_golden("nms.npz")
+    for ci in range(int(g["n_cases"])):
+        keep = pp.nms(g[f"c{ci}_dets"], float(g[f"c{ci}_thr"]))
+        assert np.array_equal(np.asarray(keep, dtype=np.int64), g[f"c{ci}_keep"]), ci
+
+
+def test_nms_iou_exactly_at_threshold_is_kept():
+    dets = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 3, 0.8], [0, 0, 9, 4, 0.7]], dtype=np.float32)
+    assert pp.nms(dets, 0.4) == [0, 1]            # IoU 0.4 kept (<=), 0.5 suppressed
+
+
+def test_estimate_norm_vs_skimage():
+    g = load_golden("umeyama.npz")
+    for lm, M in zip(g["landmarks"], g["M"]):
+        scale = max(1.0, np.abs(M).max())
+        m32, idx = align.estimate_norm(lm)
+        assert idx == 0 and m32.dtype == np.float64 and m32.shape == (2, 3)
+        assert np.abs(m32 - M).max() / scale < 2e-6          # same algorithm, LAPACK build differs
+        m64, _ = align.estimate_norm(lm, f64=True)
+        assert np.abs(m64 - M).max() / scale < 1e-5          # <= 6.6e-6 expected
+
+
+def test_cosine_vs_reference():
+    g = load_golden("cosine.npz")
+    sims = np.array([match.compute_similarity(a, b) for a, b in zip(g["a"], g["b"])])
+    assert sims.dtype == np.float32
+    # np.dot summation order is BLAS dependent: equal to a few ulp
+    assert np.abs(sims - g["sim"]).max() < 1e-6
+    assert abs(sims[0] - 1) < 1e-6 and abs(sims[1] + 1) < 1e-6 and abs(sims[3] - 1) < 1e-6
+
+
+def test_gallery_scan_semantics():
+    g = load_golden("gallery_scan.npz")
+    for thr in g["thrs"]:
+        idx = g[f"idx_thr{thr}"]
+        sim = g[f"sim_thr{thr}"]
+        for i, e in enumerate(g["emb"]):
+            j, s = match.gallery_scan(e, g["gallery"], float(thr))
+            assert j == idx[i], (thr, i)
+            assert abs(float(s) - float(sim[i])) < 1e-6
+        bj, bs = match.match_batch(g["emb"], g["gallery"], float(thr))
+        assert np.array_equal(bj, idx)
+        assert np.abs(bs - sim).max() < 1e-5
+    assert g["idx_thr0.4"][0] == 7 and g["idx_thr0.4"][2] == -1 and g["idx_thr0.4"][4] == 20
