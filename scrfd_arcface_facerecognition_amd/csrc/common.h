@@ -1,0 +1,67 @@
+// Shared internals of libfaceid.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/faceid.h"
+
+namespace fid {
+
+void set_error(const char *fmt, ...);
+
+#define FID_HIP(call)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            fid::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return FID_E_HIP;                                                            \
+        }                                                                                \
+    } while (0)
+
+#define FID_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            fid::set_error(__VA_ARGS__);       \
+            return FID_E_INVALID;              \
+        }                                      \
+    } while (0)
+
+#define FID_TRY(expr)                \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != FID_OK) return rc_; \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace fid
+
+struct fid_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    std::mutex mu;
+    // growable scratch arenas (never shrink; no allocation on the steady-state path)
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    hipEvent_t events[FID_MAX_EVENTS] = {};
+    // SCRFD post-process state
+    int cand_cap = 4096;
+    int32_t *status_dev = nullptr;  // [0] max candidates seen, [1] max survivors seen
+    int last_out_cap = 0;
+};
+
+namespace fid {
+// scratch arena `slot` with at least `bytes` bytes (grows by reallocating; contents undefined)
+int get_scratch(fid_ctx *ctx, int slot, size_t bytes, void **out);
+}  // namespace fid

@@ -1,0 +1,42 @@
+// Implicit-GEMM convolution on gfx950 MFMA -- argument block shared by net.hip and match.hip.
+#pragma once
+#include "common.h"
+
+namespace fid {
+
+enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_PRELU = 2 };
+enum : int {
+    CF_RES_UP2 = 1,   // residual is read at (oy/2, ox/2): fused nearest-2x upsample + add (PAFPN top-down)
+    CF_BORDER = 2,    // bias table has 9 border classes (exact fold of a BatchNorm that precedes a zero-padded conv)
+    CF_OUT_F32 = 4,   // store fp32 instead of fp16
+    CF_ARGMAX = 8,    // no store: per output row, atomicMax of (value, column) -- the gallery match epilogue
+};
+
+struct ConvArgs {
+    const void *in;     // fp16 [B, H, W, Cin_p]
+    const void *w;      // fp16 [w_rows][T][Cin_p]   (T = kh*kw taps, tap-major then channel)
+    const float *bias;  // fp32 [ncls][Cout_p]  (ncls = 9 with CF_BORDER else 1), may be NULL
+    const float *slope; // fp32 [Cout_p] PReLU slopes (ACT_PRELU)
+    const void *res;    // fp16 residual [B, res_H, res_W, res_Cp] or NULL
+    void *out;          // fp16/fp32 [B, Ho, Wo, Cout_p]
+    float *partial;     // split-K slabs fp32 [ksplit][M][Cout_p]
+    unsigned long long *amax;  // CF_ARGMAX: packed (sortable(value) << 32 | ~column) per row
+    int H, W, Cin_p, Ho, Wo, Cout_p, w_rows;
+    int kh, kw, stride, pad;
+    int M, T, nchunk, ksteps, ksplit, ksteps_per_split;
+    int act, flags, nsig;
+    int res_H, res_W, res_Cp;
+    int tiles_m, tiles_n;
+    unsigned in_bytes, w_bytes;
+};
+
+// fills the derived fields (T, nchunk, ksteps, tiles, split-K plan) and launches; `partial_ws`
+// must hold ksplit*M*Cout_p floats when the plan splits K (query with conv_plan first).
+struct ConvPlan {
+    int bm, bn, bk, ksplit;
+    size_t partial_bytes;
+};
+ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split);
+int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan);
+
+}  // namespace fid

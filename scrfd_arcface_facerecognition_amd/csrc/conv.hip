@@ -1,0 +1,377 @@
+// Implicit-GEMM convolution / GEMM on gfx950 matrix cores (v_mfma_f32_16x16x32_f16).
+//
+// This one kernel family is every conv of SCRFD and ArcFace (what onnxruntime's Conv/Gemm nodes do
+// inside session.run, reference models/scrfd.py:83 and models/arcface.py:51), the ArcFace FC layer
+// and -- with the arg-max epilogue -- the gallery cosine match (reference main.py:136-142).
+//
+// Data layout: activations NHWC fp16 with channels padded to a multiple of 32, weights
+// [Cout][tap][Cin] fp16, accumulation fp32.  GEMM view: rows = output pixels (M = B*Ho*Wo),
+// columns = output channels, K = taps x Cin walked tap-major in BK-channel steps.
+//
+// Workgroup = 256 threads = 4 wavefronts (one per SIMD), 2 workgroups per CU.  Per K-step the block
+// stages a [BM pixels x BK] activation tile and a [BN couts x BK] weight tile through registers
+// into LDS (buffer loads: out-of-image taps and out-of-range weight rows read as 0 through the
+// buffer descriptor's bounds check -- no branches), XOR-swizzled in 16-byte chunks so that both the
+// ds_write_b128 and the ds_read_b128 fragment reads are bank-conflict free (checked lane by lane
+// against the gfx950 bank map).  Loads for step k+1 are in flight while step k is multiplied.
+//
+// MFMA operand roles are swapped on purpose: A = weights (rows = couts), B = pixels, so a lane's
+// 4 accumulator registers are 4 CONSECUTIVE OUTPUT CHANNELS of ONE pixel -> the epilogue applies
+// bias / residual / activation on float4s and stores 8 contiguous bytes per lane into NHWC.
+//
+// Epilogue (fused, nothing else touches the tensor): + bias (optionally one of 9 border classes:
+// the exact fold of a BatchNorm that sits in front of a zero-padded conv), + residual (optionally
+// nearest-2x upsampled), ReLU / PReLU, sigmoid on the first nsig channels, fp16 or fp32 store;
+// or split-K partial slabs; or arg-max over columns.
+#include "conv.h"
+
+namespace fid {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0x7FFFFFF0u;  // beyond any descriptor's num_records -> the load returns 0
+
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+    // 16-byte-chunk XOR pattern; conflict-free for ds_read_b128 / ds_write_b128
+    return BK == 64 ? (row & 7) : ((-(row >> 2)) & 3);
+}
+
+__device__ __forceinline__ unsigned sortable(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct Pix {
+    int n, oy, ox;
+};
+
+__device__ __forceinline__ Pix decompose(const ConvArgs &a, int m) {
+    Pix p;
+    const int hw = a.Ho * a.Wo;
+    p.n = m / hw;
+    const int r = m - p.n * hw;
+    p.oy = r / a.Wo;
+    p.ox = r - p.oy * a.Wo;
+    return p;
+}
+
+// bias + residual + activation + store for 4 consecutive output channels of one pixel
+__device__ __forceinline__ void epilogue4(const ConvArgs &a, int m, int co0, f32x4 v, const Pix &p) {
+    if (a.bias) {
+        int cls = 0;
+        if (a.flags & CF_BORDER) {
+            const int yc = p.oy == 0 ? 0 : (p.oy == a.Ho - 1 ? 2 : 1);
+            const int xc = p.ox == 0 ? 0 : (p.ox == a.Wo - 1 ? 2 : 1);
+            cls = yc * 3 + xc;
+        }
+        const f32x4 b = *(const f32x4 *)(a.bias + (size_t)cls * a.Cout_p + co0);
+        v += b;
+    }
+    if (a.res) {
+        size_t roff;
+        if (a.flags & CF_RES_UP2)
+            roff = ((size_t)(p.n * a.res_H + (p.oy >> 1)) * a.res_W + (p.ox >> 1)) * a.res_Cp + co0;
+        else
+            roff = (size_t)m * a.res_Cp + co0;
+        const half4 r = *(const half4 *)((const _Float16 *)a.res + roff);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+    }
+    if (a.act == ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.f);
+    } else if (a.act == ACT_PRELU) {
+        const f32x4 s = *(const f32x4 *)(a.slope + co0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = v[i] > 0.f ? v[i] : v[i] * s[i];
+    }
+    if (a.nsig > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (co0 + i < a.nsig) v[i] = 1.f / (1.f + expf(-v[i]));
+    }
+    if (a.flags & CF_OUT_F32) {
+        *(f32x4 *)((float *)a.out + (size_t)m * a.Cout_p + co0) = v;
+    } else {
+        half4 h;
+        h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+        *(half4 *)((_Float16 *)a.out + (size_t)m * a.Cout_p + co0) = h;
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int CPR = BK / 8;     // 16-byte chunks per staged row
+    constexpr int RPP = 256 / CPR;  // rows staged per pass of the 256 threads
+    constexpr int A_LD = BM / RPP, B_LD = (BN + RPP - 1) / RPP;
+    constexpr bool B_PARTIAL = (BN % RPP) != 0;  // fewer weight rows than one staging pass (BN=32, BK=32)
+    static_assert(WM * WN == 4 && BM % RPP == 0 && (BN % RPP == 0 || BN < RPP) && MI >= 1 && NI >= 1, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *sA = (_Float16 *)smem;            // [2][BM][BK] pixels
+    _Float16 *sB = sA + 2 * BM * BK;            // [2][BN][BK] weights
+
+    // XCD-aware tile order: the dispatcher deals consecutive block ids round-robin over the 8 XCDs;
+    // re-label so that each XCD walks a contiguous run of tiles (all column tiles of a row tile
+    // first) and re-uses that row tile's activations from its own L2.  Bijective for any grid size.
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tn = L % a.tiles_n, tm = L / a.tiles_n;
+    const int split = blockIdx.y;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = tid / CPR, lch = tid % CPR;
+
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+
+    // ---- per-thread staging addresses (fixed rows for the whole K loop) ----
+    int a_off[A_LD];
+    unsigned a_mask[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; i++) {
+        const int m = tm * BM + i * RPP + lrow;
+        a_off[i] = 0;
+        a_mask[i] = 0;
+        if (m < a.M) {
+            const Pix p = decompose(a, m);
+            const int iy0 = p.oy * a.stride - a.pad, ix0 = p.ox * a.stride - a.pad;
+            a_off[i] = ((p.n * a.H + iy0) * a.W + ix0) * a.Cin_p + lch * 8;
+            unsigned mask = 0;
+            for (int t = 0; t < a.T; t++) {
+                const int dy = t / a.kw, dx = t - dy * a.kw;
+                if ((unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W) mask |= 1u << t;
+            }
+            a_mask[i] = mask;
+        }
+    }
+    int b_off[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; i++) {
+        const int co = tn * BN + i * RPP + lrow;
+        b_off[i] = (co < a.w_rows && (!B_PARTIAL || lrow < BN)) ? co * a.T * a.Cin_p + lch * 8 : -1;
+    }
+
+    const int ks_begin = split * a.ksteps_per_split;
+    const int ks_end = min(a.ksteps, ks_begin + a.ksteps_per_split);
+    int tap = ks_begin / a.nchunk, ch = ks_begin - tap * a.nchunk;
+    int tdy = tap / a.kw, tdx = tap - tdy * a.kw;
+
+    u32x4 ra[A_LD], rb[B_LD];
+    auto issue_loads = [&]() {
+        const int adelta = (tdy * a.W + tdx) * a.Cin_p + ch * BK;
+        const int bdelta = tap * a.Cin_p + ch * BK;
+#pragma unroll
+        for (int i = 0; i < A_LD; i++) {
+            const unsigned vo = ((a_mask[i] >> tap) & 1u) ? (unsigned)(a_off[i] + adelta) * 2u : OOB;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; i++) {
+            const unsigned vo = b_off[i] >= 0 ? (unsigned)(b_off[i] + bdelta) * 2u : OOB;
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; i++) {
+            const int row = i * RPP + lrow;
+            *(u32x4 *)(sA + (buf * BM + row) * BK + ((lch ^ swz<BK>(row)) * 8)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; i++) {
+            const int row = i * RPP + lrow;
+            if (!B_PARTIAL || row < BN) *(u32x4 *)(sB + (buf * BN + row) * BK + ((lch ^ swz<BK>(row)) * 8)) = rb[i];
+        }
+    };
+    auto advance = [&]() {
+        if (++ch == a.nchunk) {
+            ch = 0;
+            ++tap;
+            if (++tdx == a.kw) { tdx = 0; ++tdy; }
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (ks_begin < ks_end) {
+        issue_loads();
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int ks = ks_begin; ks < ks_end; ks++) {
+        const int cur = (ks - ks_begin) & 1;
+        const bool more = ks + 1 < ks_end;
+        if (more) {
+            advance();
+            issue_loads();
+        }
+        const _Float16 *cA = sA + cur * BM * BK, *cB = sB + cur * BN * BK;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; kk++) {
+            half8 wf[NI], pf[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int row = wn * TN + ni * 16 + frow;
+                wf[ni] = *(const half8 *)(cB + row * BK + (((kk * 4 + fq) ^ swz<BK>(row)) * 8));
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int row = wm * TM + mi * 16 + frow;
+                pf[mi] = *(const half8 *)(cA + row * BK + (((kk * 4 + fq) ^ swz<BK>(row)) * 8));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds couts co0..co0+3 (rows of D) of pixel `m` (column of D) ----
+    if (a.flags & CF_ARGMAX) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            const int m = tm * BM + wm * TM + mi * 16 + frow;
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int co0 = tn * BN + wn * TN + ni * 16 + fq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (co0 + j < a.Cout_p) {
+                        const unsigned long long key = ((unsigned long long)sortable(acc[ni][mi][j]) << 32) | (unsigned)(~(unsigned)(co0 + j));
+                        best = key > best ? key : best;
+                    }
+                }
+            }
+            // the 4 lanes l, l^16, l^32, l^48 hold the same pixel
+            unsigned long long o = __shfl_xor(best, 16);
+            best = o > best ? o : best;
+            o = __shfl_xor(best, 32);
+            best = o > best ? o : best;
+            if (fq == 0 && m < a.M) atomicMax(a.amax + m, best);
+        }
+        return;
+    }
+    const bool need_pix = (a.flags & (CF_BORDER | CF_RES_UP2)) != 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+        const int m = tm * BM + wm * TM + mi * 16 + frow;
+        if (m >= a.M) continue;
+        Pix p{0, 0, 0};
+        if (need_pix) p = decompose(a, m);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int co0 = tn * BN + wn * TN + ni * 16 + fq * 4;
+            if (co0 >= a.Cout_p) continue;
+            if (a.ksplit > 1)
+                *(f32x4 *)(a.partial + ((size_t)split * a.M + m) * a.Cout_p + co0) = acc[ni][mi];
+            else
+                epilogue4(a, m, co0, acc[ni][mi], p);
+        }
+    }
+}
+
+// second pass of a split-K conv: sum the slabs in a fixed order (bit-reproducible), then the epilogue
+__global__ void __launch_bounds__(256) splitk_epilogue(const ConvArgs a) {
+    const int c4 = a.Cout_p >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)a.M * c4) return;
+    const int m = (int)(idx / c4), co0 = (int)(idx - (long long)m * c4) * 4;
+    f32x4 v = *(const f32x4 *)(a.partial + (size_t)m * a.Cout_p + co0);
+    for (int s = 1; s < a.ksplit; s++) v += *(const f32x4 *)(a.partial + ((size_t)s * a.M + m) * a.Cout_p + co0);
+    Pix p{0, 0, 0};
+    if (a.flags & (CF_BORDER | CF_RES_UP2)) p = decompose(a, m);
+    epilogue4(a, m, co0, v, p);
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch_cfg(fid_ctx *ctx, const ConvArgs &a) {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * BK * 2;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        FID_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<BM, BN, BK, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, a.ksplit);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), lds, ctx->stream, a);
+    return FID_OK;
+}
+
+}  // namespace
+
+ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
+    ConvPlan p;
+    p.bk = (a.Cin_p % 64 == 0) ? 64 : 32;
+    const int ksteps = a.kh * a.kw * (a.Cin_p / p.bk);
+    if (p.bk == 64) {
+        p.bn = a.Cout_p >= 128 ? 128 : 64;
+        p.bm = 128;
+        auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
+        if (tiles(p.bm, p.bn) < 2LL * num_cus && p.bn == 128) p.bn = 64;
+        if (tiles(p.bm, p.bn) < 2LL * num_cus) p.bm = 64, p.bn = 64;
+    } else {
+        p.bm = 128;
+        p.bn = a.Cout_p >= 128 ? 128 : (a.Cout_p > 32 ? 64 : 32);
+        auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
+        if (tiles(p.bm, p.bn) < 2LL * num_cus && p.bn == 128) p.bn = 64;
+    }
+    const long long t = (long long)cdiv(a.M, p.bm) * cdiv(a.Cout_p, p.bn);
+    p.ksplit = 1;
+    if (allow_split && !(a.flags & CF_ARGMAX) && t < num_cus && ksteps >= 8) {
+        int want = (int)((2LL * num_cus + t - 1) / t);
+        p.ksplit = std::max(1, std::min(want, ksteps / 4));
+    }
+    p.partial_bytes = p.ksplit > 1 ? (size_t)p.ksplit * a.M * a.Cout_p * 4 : 0;
+    return p;
+}
+
+int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
+    a.T = a.kh * a.kw;
+    FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);
+    FID_REQUIRE(a.Cin_p % plan.bk == 0 && a.Cout_p % 4 == 0, "conv: channel padding (Cin_p=%d Cout_p=%d)", a.Cin_p, a.Cout_p);
+    FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB; lower the batch");
+    a.nchunk = a.Cin_p / plan.bk;
+    a.ksteps = a.T * a.nchunk;
+    a.ksplit = plan.ksplit;
+    a.ksteps_per_split = cdiv(a.ksteps, a.ksplit);
+    a.ksplit = cdiv(a.ksteps, a.ksteps_per_split);
+    a.tiles_m = cdiv(a.M, plan.bm);
+    a.tiles_n = cdiv(a.Cout_p, plan.bn);
+    FID_REQUIRE(a.ksplit == 1 || a.partial, "conv: split-K without a partial buffer");
+    int rc = FID_E_INVALID;
+    const int key = plan.bm * 1000000 + plan.bn * 1000 + plan.bk;
+    switch (key) {
+        case 128128064: rc = launch_cfg<128, 128, 64, 2, 2>(ctx, a); break;
+        case 128064064: rc = launch_cfg<128, 64, 64, 2, 2>(ctx, a); break;
+        case 64064064: rc = launch_cfg<64, 64, 64, 2, 2>(ctx, a); break;
+        case 128128032: rc = launch_cfg<128, 128, 32, 2, 2>(ctx, a); break;
+        case 128064032: rc = launch_cfg<128, 64, 32, 2, 2>(ctx, a); break;
+        case 128032032: rc = launch_cfg<128, 32, 32, 4, 1>(ctx, a); break;
+        default: set_error("conv: no kernel for tile %dx%dx%d", plan.bm, plan.bn, plan.bk); return FID_E_INVALID;
+    }
+    FID_TRY(rc);
+    if (a.ksplit > 1) {
+        const long long n = (long long)a.M * (a.Cout_p / 4);
+        hipLaunchKernelGGL(splitk_epilogue, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, ctx->stream, a);
+    }
+    FID_HIP(hipGetLastError());
+    return FID_OK;
+}
+
+}  // namespace fid

@@ -1,0 +1,149 @@
+// Context, device memory, events.  Plain HIP runtime calls; no torch anywhere in this library.
+#include "common.h"
+
+namespace fid {
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+int get_scratch(fid_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            FID_HIP(hipStreamSynchronize(ctx->stream));
+            FID_HIP(hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        size_t want = bytes + bytes / 4 + 4096;
+        FID_HIP(hipMalloc(&ctx->scratch[slot], want));
+        ctx->scratch_bytes[slot] = want;
+    }
+    *out = ctx->scratch[slot];
+    return FID_OK;
+}
+}  // namespace fid
+
+extern "C" {
+
+int fid_abi_version(void) { return FID_ABI_VERSION; }
+const char *fid_last_error(void) { return fid::g_err.c_str(); }
+
+int fid_device_count(int *count) {
+    FID_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    *count = n;
+    return FID_OK;
+}
+
+int fid_ctx_create(int device, void *stream, fid_ctx **out) {
+    FID_REQUIRE(out, "out is NULL");
+    int n = 0;
+    FID_HIP(hipGetDeviceCount(&n));
+    FID_REQUIRE(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
+    FID_HIP(hipSetDevice(device));
+    fid_ctx *c = new fid_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        FID_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    FID_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    FID_HIP(hipMalloc((void **)&c->status_dev, 64));
+    FID_HIP(hipMemsetAsync(c->status_dev, 0, 64, c->stream));
+    *out = c;
+    return FID_OK;
+}
+
+int fid_ctx_destroy(fid_ctx *ctx) {
+    if (!ctx) return FID_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 4; i++)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    for (int i = 0; i < FID_MAX_EVENTS; i++)
+        if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
+    if (ctx->status_dev) (void)hipFree(ctx->status_dev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FID_OK;
+}
+
+int fid_sync(fid_ctx *ctx) {
+    FID_REQUIRE(ctx, "ctx is NULL");
+    FID_HIP(hipStreamSynchronize(ctx->stream));
+    return FID_OK;
+}
+
+int fid_device_name(fid_ctx *ctx, char *buf, int buflen) {
+    FID_REQUIRE(ctx && buf && buflen > 0, "bad args");
+    hipDeviceProp_t prop;
+    FID_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, buflen, "%s|%s|cus=%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return FID_OK;
+}
+
+int fid_malloc(fid_ctx *ctx, size_t bytes, void **dptr) {
+    FID_REQUIRE(ctx && dptr, "bad args");
+    FID_HIP(hipSetDevice(ctx->device));
+    FID_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return FID_OK;
+}
+
+int fid_free(fid_ctx *ctx, void *dptr) {
+    FID_REQUIRE(ctx, "ctx is NULL");
+    if (!dptr) return FID_OK;
+    FID_HIP(hipStreamSynchronize(ctx->stream));
+    FID_HIP(hipFree(dptr));
+    return FID_OK;
+}
+
+int fid_memcpy_h2d(fid_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    FID_REQUIRE(ctx && (bytes == 0 || (dst && src)), "bad args");
+    if (bytes == 0) return FID_OK;
+    // pageable source: hipMemcpyAsync stages it and returns once the source may be reused
+    FID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return FID_OK;
+}
+
+int fid_memcpy_d2h(fid_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    FID_REQUIRE(ctx && (bytes == 0 || (dst && src)), "bad args");
+    if (bytes == 0) return FID_OK;
+    FID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FID_HIP(hipStreamSynchronize(ctx->stream));
+    return FID_OK;
+}
+
+int fid_memset(fid_ctx *ctx, void *dst, int value, size_t bytes) {
+    FID_REQUIRE(ctx && (bytes == 0 || dst), "bad args");
+    if (bytes == 0) return FID_OK;
+    FID_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return FID_OK;
+}
+
+int fid_event_record(fid_ctx *ctx, int slot) {
+    FID_REQUIRE(ctx && slot >= 0 && slot < FID_MAX_EVENTS, "bad event slot %d", slot);
+    if (!ctx->events[slot]) FID_HIP(hipEventCreate(&ctx->events[slot]));
+    FID_HIP(hipEventRecord(ctx->events[slot], ctx->stream));
+    return FID_OK;
+}
+
+int fid_event_elapsed_ms(fid_ctx *ctx, int a, int b, float *ms) {
+    FID_REQUIRE(ctx && ms && a >= 0 && b >= 0 && a < FID_MAX_EVENTS && b < FID_MAX_EVENTS, "bad args");
+    FID_REQUIRE(ctx->events[a] && ctx->events[b], "event slot not recorded");
+    FID_HIP(hipEventSynchronize(ctx->events[b]));
+    FID_HIP(hipEventElapsedTime(ms, ctx->events[a], ctx->events[b]));
+    return FID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// Layer-table format shared with scrfd_arcface_facerecognition_amd/lower.py (keep in sync).
+#pragma once
+#include "conv.h"
+
+namespace fid {
+
+enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4 };
+
+// int32 word indices inside one op record (FID_OP_WORDS = 32 words)
+enum : int {
+    W_TYPE = 0,
+    W_SRC = 1,    // tensor id, -1 = the uint8 BGR input images
+    W_DST = 2,
+    W_RES = 3,    // residual tensor id or -1
+    W_KH = 4,
+    W_KW = 5,
+    W_STRIDE = 6,
+    W_PAD = 7,
+    W_CIN = 8,    // logical channels (cost accounting)
+    W_COUT = 9,
+    W_ACT = 10,
+    W_FLAGS = 11,  // CF_* bits
+    W_NSIG = 12,
+    W_WOFF = 13,   // byte offset of the packed weights inside the blob
+    W_WBYTES = 14,
+    W_BOFF = 15,   // bias table offset or -1
+    W_SOFF = 16,   // PReLU slope table offset or -1
+    W_WROWS = 17,  // rows (output channels) present in the packed weights
+    W_GROUPS = 18, // 1, or cin for depthwise
+};
+
+// int32 word indices of one tensor record (FID_TENSOR_WORDS = 8 words)
+enum : int { T_C = 0, T_CP = 1, T_H = 2, T_W = 3, T_DTYPE = 4, T_SLOT = 5, T_FLAGS = 6 };
+
+}  // namespace fid

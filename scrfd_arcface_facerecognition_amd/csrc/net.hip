@@ -1,0 +1,369 @@
+// Conv-net executor: runs a layer table (lower.py) as a fixed sequence of HIP kernel launches on the
+// context's stream.  This is what replaces onnxruntime.InferenceSession.run on the hot path
+// (reference models/scrfd.py:83, models/arcface.py:51) together with the blob conversion that
+// precedes it (cv2.dnn.blobFromImage(s), scrfd.py:76-82 / arcface.py:44-50), which is fused into
+// the first convolution: the stem reads the uint8 BGR pixels directly.
+//
+// Memory: activations live in a few slot buffers (liveness-planned by lower.py) sized for
+// max_batch; weights are one packed blob.  Nothing is allocated on the steady-state path.
+#include "net.h"
+
+struct fid_net {
+    int n_ops = 0, n_tensors = 0, in_h = 0, in_w = 0, max_batch = 0;
+    std::vector<int32_t> ops, tensors;
+    void *blob = nullptr;
+    size_t blob_bytes = 0;
+    std::vector<void *> slots;
+    std::vector<size_t> slot_bytes_per_image;
+    double macs_per_image = 0;
+    hipEvent_t *prof_events = nullptr;
+    int n_prof_events = 0;
+};
+
+namespace fid {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// ---- first conv: uint8 BGR image -> fp16 NHWC, 3x3, stride 1|2, pad 1, fused normalisation --------
+// blob = (pixel - 127.5) * scale with BGR->RGB swap (A.4).  The kernel works on the exact integers
+// (2*pixel - 255); scale/2, the channel swap and the following BatchNorm are folded into the fp32
+// weights by lower.py.  Zero padding pads the *normalised* blob, i.e. contributes exactly 0.
+// VALU kernel (K = 27 is too short for the matrix cores to matter: 0.3 % / 0.6 % of the net's MACs);
+// weights are wave-uniform -> scalar loads, one FMA per (tap, channel, cout).
+template <int CPW>
+__global__ void __launch_bounds__(256) stem_conv3x3(const uint8_t *__restrict__ img, const float *__restrict__ w,
+                                                    const float *__restrict__ bias, const float *__restrict__ slope,
+                                                    _Float16 *__restrict__ out, int H, int W, int Ho, int Wo, int Cout_p,
+                                                    int stride, int act, long long total_pix) {
+    const long long pix = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (pix >= total_pix) return;
+    const int hw = Ho * Wo;
+    const int n = (int)(pix / hw);
+    const int r = (int)(pix - (long long)n * hw);
+    const int oy = r / Wo, ox = r - oy * Wo;
+    const int iy0 = oy * stride - 1, ix0 = ox * stride - 1;
+    float x[27];
+    const uint8_t *base = img + (size_t)n * H * W * 3;
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const int iy = iy0 + dy, ix = ix0 + dx;
+            const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const uint8_t *p = base + ((size_t)(in ? iy : 0) * W + (in ? ix : 0)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) x[(dy * 3 + dx) * 3 + c] = in ? (float)(2 * (int)p[c] - 255) : 0.f;
+        }
+    }
+    _Float16 res[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+        const int co = cg * CPW + c;
+        const float *wr = w + co * 27;
+        float acc = bias[co];
+#pragma unroll
+        for (int k = 0; k < 27; k++) acc = fmaf(x[k], wr[k], acc);
+        if (act == ACT_RELU) acc = fmaxf(acc, 0.f);
+        else if (act == ACT_PRELU) acc = acc > 0.f ? acc : acc * slope[co];
+        res[c] = (_Float16)acc;
+    }
+    _Float16 *o = out + (size_t)pix * Cout_p + cg * CPW;
+#pragma unroll
+    for (int c = 0; c < CPW; c += 8) *(half8 *)(o + c) = *(half8 *)(res + c);
+}
+
+// ---- max pool k x k / stride / pad on NHWC fp16, 8 channels (16 B) per thread ----------------------
+__global__ void __launch_bounds__(256) maxpool_nhwc(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int H, int W,
+                                                    int Ho, int Wo, int Cp, int k, int stride, int pad, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = Cp >> 3;
+    const int cg = (int)(idx % c8);
+    const long long pix = idx / c8;
+    const int hw = Ho * Wo;
+    const int n = (int)(pix / hw);
+    const int r = (int)(pix - (long long)n * hw);
+    const int oy = r / Wo, ox = r - oy * Wo;
+    half8 m;
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] = (_Float16)(-65504.f);
+    for (int dy = 0; dy < k; dy++) {
+        const int iy = oy * stride - pad + dy;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int dx = 0; dx < k; dx++) {
+            const int ix = ox * stride - pad + dx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const half8 v = *(const half8 *)(in + ((size_t)(n * H + iy) * W + ix) * Cp + cg * 8);
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[i] = v[i] > m[i] ? v[i] : m[i];
+        }
+    }
+    *(half8 *)(out + (size_t)pix * Cp + cg * 8) = m;
+}
+
+// ---- depthwise k x k conv on NHWC fp16 (SCRFD-500M / MobileFaceNet), 8 channels per thread ---------
+// weights fp32 [k*k][Cp] (BatchNorm folded), bias fp32 [Cp]; HBM-bound: k*k MACs per loaded element.
+__global__ void __launch_bounds__(256) dwconv_nhwc(const _Float16 *__restrict__ in, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, const float *__restrict__ slope,
+                                                   _Float16 *__restrict__ out, int H, int W, int Ho, int Wo, int Cp, int k,
+                                                   int stride, int pad, int act, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c8 = Cp >> 3;
+    const int cg = (int)(idx % c8);
+    const long long pix = idx / c8;
+    const int hw = Ho * Wo;
+    const int n = (int)(pix / hw);
+    const int r = (int)(pix - (long long)n * hw);
+    const int oy = r / Wo, ox = r - oy * Wo;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = bias[cg * 8 + i];
+    for (int dy = 0; dy < k; dy++) {
+        const int iy = oy * stride - pad + dy;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int dx = 0; dx < k; dx++) {
+            const int ix = ox * stride - pad + dx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const half8 v = *(const half8 *)(in + ((size_t)(n * H + iy) * W + ix) * Cp + cg * 8);
+            const float *wr = w + (size_t)(dy * k + dx) * Cp + cg * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[i] = fmaf((float)v[i], wr[i], acc[i]);
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float a = acc[i];
+        if (act == ACT_RELU) a = fmaxf(a, 0.f);
+        else if (act == ACT_PRELU) a = a > 0.f ? a : a * slope[cg * 8 + i];
+        o[i] = (_Float16)a;
+    }
+    *(half8 *)(out + (size_t)pix * Cp + cg * 8) = o;
+}
+
+struct TensorView {
+    void *ptr;
+    int C, Cp, H, W, dtype;
+};
+
+TensorView view(const fid_net *net, int id) {
+    const int32_t *t = &net->tensors[(size_t)id * FID_TENSOR_WORDS];
+    return TensorView{net->slots[t[T_SLOT]], t[T_C], t[T_CP], t[T_H], t[T_W], t[T_DTYPE]};
+}
+
+int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int batch, void *partial_ws) {
+    const int32_t *op = &net->ops[(size_t)oi * FID_OP_WORDS];
+    const char *blob = (const char *)net->blob;
+    const TensorView dst = view(net, op[W_DST]);
+    const float *bias = op[W_BOFF] >= 0 ? (const float *)(blob + op[W_BOFF]) : nullptr;
+    const float *slope = op[W_SOFF] >= 0 ? (const float *)(blob + op[W_SOFF]) : nullptr;
+    switch (op[W_TYPE]) {
+        case OP_STEM: {
+            const long long total = (long long)batch * dst.H * dst.W;
+            const int cpw = dst.Cp / 4;
+            const float *w = (const float *)(blob + op[W_WOFF]);
+            dim3 grid((unsigned)cdiv64(total, 64));
+#define STEM(CPW) hipLaunchKernelGGL(stem_conv3x3<CPW>, grid, dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, dst.Cp, op[W_STRIDE], op[W_ACT], total)
+            if (cpw == 8) STEM(8);
+            else if (cpw == 16) STEM(16);
+            else if (cpw == 32) STEM(32);
+            else { set_error("stem: Cout_p=%d unsupported", dst.Cp); return FID_E_INVALID; }
+#undef STEM
+            break;
+        }
+        case OP_CONV: {
+            const TensorView src = view(net, op[W_SRC]);
+            ConvArgs a{};
+            a.in = src.ptr;
+            a.w = blob + op[W_WOFF];
+            a.bias = bias;
+            a.slope = slope;
+            a.out = dst.ptr;
+            a.H = src.H; a.W = src.W; a.Cin_p = src.Cp;
+            a.Ho = dst.H; a.Wo = dst.W; a.Cout_p = dst.Cp;
+            a.w_rows = op[W_WROWS];
+            a.kh = op[W_KH]; a.kw = op[W_KW]; a.stride = op[W_STRIDE]; a.pad = op[W_PAD];
+            a.M = batch * dst.H * dst.W;
+            a.act = op[W_ACT]; a.flags = op[W_FLAGS]; a.nsig = op[W_NSIG];
+            if (dst.dtype == 1) a.flags |= CF_OUT_F32;
+            if (op[W_RES] >= 0) {
+                const TensorView r = view(net, op[W_RES]);
+                a.res = r.ptr; a.res_H = r.H; a.res_W = r.W; a.res_Cp = r.Cp;
+            }
+            a.in_bytes = (unsigned)((size_t)batch * src.H * src.W * src.Cp * 2);
+            a.w_bytes = (unsigned)op[W_WBYTES];
+            const ConvPlan plan = conv_plan(a, ctx->num_cus, partial_ws != nullptr);
+            a.partial = (float *)partial_ws;
+            FID_TRY(conv_launch(ctx, a, plan));
+            break;
+        }
+        case OP_MAXPOOL: {
+            const TensorView src = view(net, op[W_SRC]);
+            const long long total = (long long)batch * dst.H * dst.W * (dst.Cp / 8);
+            hipLaunchKernelGGL(maxpool_nhwc, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, (const _Float16 *)src.ptr,
+                               (_Float16 *)dst.ptr, src.H, src.W, dst.H, dst.W, dst.Cp, op[W_KH], op[W_STRIDE], op[W_PAD], total);
+            break;
+        }
+        case OP_DWCONV: {
+            const TensorView src = view(net, op[W_SRC]);
+            const long long total = (long long)batch * dst.H * dst.W * (dst.Cp / 8);
+            hipLaunchKernelGGL(dwconv_nhwc, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, (const _Float16 *)src.ptr,
+                               (const float *)(blob + op[W_WOFF]), bias, slope, (_Float16 *)dst.ptr, src.H, src.W, dst.H, dst.W,
+                               dst.Cp, op[W_KH], op[W_STRIDE], op[W_PAD], op[W_ACT], total);
+            break;
+        }
+        default:
+            set_error("net: unknown op type %d at %d", op[W_TYPE], oi);
+            return FID_E_INVALID;
+    }
+    return FID_OK;
+}
+
+// worst-case split-K workspace over all ops at this batch
+size_t partial_need(fid_ctx *ctx, fid_net *net, int batch) {
+    size_t need = 0;
+    for (int oi = 0; oi < net->n_ops; oi++) {
+        const int32_t *op = &net->ops[(size_t)oi * FID_OP_WORDS];
+        if (op[W_TYPE] != OP_CONV) continue;
+        const TensorView src = view(net, op[W_SRC]), dst = view(net, op[W_DST]);
+        ConvArgs a{};
+        a.Cin_p = src.Cp; a.Cout_p = dst.Cp; a.kh = op[W_KH]; a.kw = op[W_KW];
+        a.M = batch * dst.H * dst.W; a.flags = op[W_FLAGS];
+        need = std::max(need, conv_plan(a, ctx->num_cus, true).partial_bytes);
+    }
+    return need;
+}
+
+int run_all(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float *op_ms) {
+    FID_REQUIRE(ctx && net && images, "NULL argument");
+    FID_REQUIRE(batch > 0 && batch <= net->max_batch, "batch %d outside [1, %d]", batch, net->max_batch);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    void *partial_ws = nullptr;
+    const size_t need = partial_need(ctx, net, batch);
+    if (need) FID_TRY(get_scratch(ctx, 1, need, &partial_ws));
+    if (op_ms) {
+        if (net->n_prof_events < net->n_ops + 1) {
+            net->prof_events = new hipEvent_t[net->n_ops + 1];
+            for (int i = 0; i <= net->n_ops; i++) FID_HIP(hipEventCreate(&net->prof_events[i]));
+            net->n_prof_events = net->n_ops + 1;
+        }
+        FID_HIP(hipEventRecord(net->prof_events[0], ctx->stream));
+    }
+    for (int oi = 0; oi < net->n_ops; oi++) {
+        FID_TRY(run_op(ctx, net, oi, images, batch, need ? partial_ws : nullptr));
+        if (op_ms) FID_HIP(hipEventRecord(net->prof_events[oi + 1], ctx->stream));
+    }
+    FID_HIP(hipGetLastError());
+    if (op_ms) {
+        FID_HIP(hipEventSynchronize(net->prof_events[net->n_ops]));
+        for (int oi = 0; oi < net->n_ops; oi++) FID_HIP(hipEventElapsedTime(&op_ms[oi], net->prof_events[oi], net->prof_events[oi + 1]));
+    }
+    return FID_OK;
+}
+
+}  // namespace
+}  // namespace fid
+
+extern "C" {
+
+int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *tensors, int n_tensors, const void *blob,
+                   size_t blob_bytes, int in_h, int in_w, int max_batch, fid_net **out) {
+    using namespace fid;
+    FID_REQUIRE(ctx && ops && tensors && blob && out, "NULL argument");
+    FID_REQUIRE(n_ops > 0 && n_tensors > 0 && max_batch > 0 && in_h > 0 && in_w > 0, "bad sizes");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));
+    fid_net *net = new fid_net();
+    net->n_ops = n_ops; net->n_tensors = n_tensors; net->in_h = in_h; net->in_w = in_w; net->max_batch = max_batch;
+    net->ops.assign(ops, ops + (size_t)n_ops * FID_OP_WORDS);
+    net->tensors.assign(tensors, tensors + (size_t)n_tensors * FID_TENSOR_WORDS);
+    int n_slots = 0;
+    for (int t = 0; t < n_tensors; t++) {
+        const int32_t *tt = &net->tensors[(size_t)t * FID_TENSOR_WORDS];
+        if (tt[T_SLOT] < 0 || tt[T_CP] % 8 != 0 || tt[T_H] <= 0 || tt[T_W] <= 0) {
+            delete net;
+            set_error("tensor %d: bad record", t);
+            return FID_E_INVALID;
+        }
+        n_slots = std::max(n_slots, tt[T_SLOT] + 1);
+    }
+    net->slot_bytes_per_image.assign(n_slots, 0);
+    for (int t = 0; t < n_tensors; t++) {
+        const int32_t *tt = &net->tensors[(size_t)t * FID_TENSOR_WORDS];
+        const size_t b = (size_t)tt[T_H] * tt[T_W] * tt[T_CP] * (tt[T_DTYPE] == 1 ? 4 : 2);
+        net->slot_bytes_per_image[tt[T_SLOT]] = std::max(net->slot_bytes_per_image[tt[T_SLOT]], b);
+    }
+    for (int oi = 0; oi < n_ops; oi++) {
+        const int32_t *op = &net->ops[(size_t)oi * FID_OP_WORDS];
+        const bool ok = op[W_DST] >= 0 && op[W_DST] < n_tensors && op[W_SRC] >= -1 && op[W_SRC] < n_tensors &&
+                        op[W_RES] >= -1 && op[W_RES] < n_tensors && op[W_WOFF] >= -1 &&
+                        (op[W_WOFF] < 0 || (size_t)op[W_WOFF] + (size_t)op[W_WBYTES] <= blob_bytes) &&
+                        (op[W_TYPE] == OP_STEM) == (op[W_SRC] == -1);
+        if (!ok) {
+            delete net;
+            set_error("op %d: bad record", oi);
+            return FID_E_INVALID;
+        }
+        const int32_t *dt = &net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS];
+        if (op[W_TYPE] == OP_CONV || op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_DWCONV)
+            net->macs_per_image += (double)dt[T_H] * dt[T_W] * op[W_COUT] * (op[W_CIN] / std::max(1, op[W_GROUPS])) * op[W_KH] * op[W_KW];
+    }
+    for (int s = 0; s < n_slots; s++) {
+        const size_t bytes = net->slot_bytes_per_image[s] * (size_t)max_batch;
+        if (bytes > 0x7FFFFFF0ull) {
+            delete net;
+            set_error("activation slot %d needs %zu bytes at max_batch=%d (> 2 GiB addressable per tensor): lower max_batch", s, bytes, max_batch);
+            return FID_E_INVALID;
+        }
+    }
+    net->slots.assign(n_slots, nullptr);
+    for (int s = 0; s < n_slots; s++) FID_HIP(hipMalloc(&net->slots[s], net->slot_bytes_per_image[s] * (size_t)max_batch + 256));
+    FID_HIP(hipMalloc(&net->blob, blob_bytes + 256));
+    net->blob_bytes = blob_bytes;
+    FID_HIP(hipMemcpy(net->blob, blob, blob_bytes, hipMemcpyHostToDevice));
+    *out = net;
+    return FID_OK;
+}
+
+int fid_net_destroy(fid_ctx *ctx, fid_net *net) {
+    if (!net) return FID_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : net->slots)
+        if (p) (void)hipFree(p);
+    if (net->blob) (void)hipFree(net->blob);
+    if (net->prof_events) {
+        for (int i = 0; i < net->n_prof_events; i++) (void)hipEventDestroy(net->prof_events[i]);
+        delete[] net->prof_events;
+    }
+    delete net;
+    return FID_OK;
+}
+
+int fid_net_run(fid_ctx *ctx, fid_net *net, const uint8_t *images_dev, int batch) {
+    return fid::run_all(ctx, net, images_dev, batch, nullptr);
+}
+
+int fid_net_run_profiled(fid_ctx *ctx, fid_net *net, const uint8_t *images_dev, int batch, float *op_ms) {
+    FID_REQUIRE(op_ms, "op_ms is NULL");
+    return fid::run_all(ctx, net, images_dev, batch, op_ms);
+}
+
+int fid_net_tensor(fid_net *net, int tensor_id, void **dptr, int dims[4], int *dtype) {
+    FID_REQUIRE(net && tensor_id >= 0 && tensor_id < net->n_tensors, "bad tensor id %d", tensor_id);
+    const fid::TensorView v = fid::view(net, tensor_id);
+    if (dptr) *dptr = v.ptr;
+    if (dims) { dims[0] = v.H; dims[1] = v.W; dims[2] = v.C; dims[3] = v.Cp; }
+    if (dtype) *dtype = v.dtype;
+    return FID_OK;
+}
+
+int fid_net_macs(fid_net *net, double *macs_per_image) {
+    FID_REQUIRE(net && macs_per_image, "NULL argument");
+    *macs_per_image = net->macs_per_image;
+    return FID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+"""Host-side handles over the C-ABI: a compiled conv net, the SCRFD post-process, alignment and the
+gallery.  Everything here only moves pointers and shapes; all arithmetic happens in libfaceid.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import Context, DeviceBuffer, check
+from .archs import ARCHS, ONNX_BASENAMES, Net, synth_params
+from .lower import Lowered, lower
+
+
+class CompiledNet:
+    """fid_net: layer table + packed weights resident on one device.  The session.run replacement
+    (reference models/scrfd.py:83, models/arcface.py:51)."""
+
+    def __init__(self, ctx: Context, net: Net, params: Dict[str, np.ndarray], max_batch: int = 64):
+        self.ctx = ctx
+        self.net = net
+        self.low: Lowered = lower(net, params)
+        self.max_batch = int(max_batch)
+        ops = np.ascontiguousarray(self.low.ops, dtype=np.int32)
+        tens = np.ascontiguousarray(self.low.tensors, dtype=np.int32)
+        h = C.c_void_p()
+        blob = self.low.blob
+        check(ctx.lib.fid_net_create(ctx.handle, ops.ctypes.data_as(_lib.c_i32_p), ops.shape[0],
+                                     tens.ctypes.data_as(_lib.c_i32_p), tens.shape[0], blob, len(blob),
+                                     net.in_hw[0], net.in_hw[1], self.max_batch, C.byref(h)))
+        self.handle = h
+        self.in_hw = tuple(net.in_hw)
+        self._in_buf: Optional[DeviceBuffer] = None
+
+    # -- running ----------------------------------------------------------------------------
+    def run_device(self, images_dev, batch: int):
+        """images_dev: device pointer to uint8 BGR [batch, H, W, 3]"""
+        check(self.ctx.lib.fid_net_run(self.ctx.handle, self.handle, _lib._ptr(images_dev), int(batch)))
+
+    def run(self, images: np.ndarray):
+        """images: uint8 [B,H,W,3] host array (B <= max_batch)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        assert images.ndim == 4 and images.shape[1:3] == self.in_hw and images.shape[3] == 3, images.shape
+        if self._in_buf is None or self._in_buf.nbytes < images.nbytes:
+            self._in_buf = self.ctx.empty((self.max_batch,) + images.shape[1:], np.uint8)
+        check(self.ctx.lib.fid_memcpy_h2d(self.ctx.handle, C.c_void_p(self._in_buf.ptr),
+                                          images.ctypes.data_as(C.c_void_p), images.nbytes))
+        self.ctx.sync()
+        self.run_device(self._in_buf, images.shape[0])
+        return images.shape[0]
+
+    def run_profiled(self, images_dev, batch: int) -> np.ndarray:
+        ms = np.zeros(len(self.low.op_names), dtype=np.float32)
+        check(self.ctx.lib.fid_net_run_profiled(self.ctx.handle, self.handle, _lib._ptr(images_dev), int(batch),
+                                                ms.ctypes.data_as(_lib.c_f32_p)))
+        return ms
+
+    # -- tensors ----------------------------------------------------------------------------
+    def tensor(self, name: str):
+        """(device pointer, (H, W, C, C_stored), dtype) of a tensor of the last run."""
+        p = C.c_void_p()
+        dims = (C.c_int * 4)()
+        dt = C.c_int()
+        check(self.ctx.lib.fid_net_tensor(self.handle, self.low.tensor_id[name], C.byref(p), dims, C.byref(dt)))
+        return p.value, tuple(dims), (np.float32 if dt.value == 1 else np.float16)
+
+    def read(self, name: str, batch: int) -> np.ndarray:
+        """Download tensor `name` as float32 [batch, H, W, C] (channel padding stripped)."""
+        ptr, (H, W, Cc, Cp), dt = self.tensor(name)
+        buf = self.ctx.borrow(ptr, (batch, H, W, Cp), dt)
+        return buf.download()[..., :Cc].astype(np.float32)
+
+    def macs_per_image(self) -> float:
+        v = C.c_double()
+        check(self.ctx.lib.fid_net_macs(self.handle, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.fid_net_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+def resolve_model(model_path: str, in_hw=None):
+    """model_path -> (Net, params).  Accepted:
+      'synthetic:<arch>[?seed=N]'   seeded random-init weights of a known architecture
+      '<file>.npz'                  parameters saved by save_params() (+ key '__arch__')
+      '<file>.onnx'                 a real ONNX file (weights read by onnx_reader, no onnx/ORT needed)
+    Like onnxruntime, a missing file raises (reference models/scrfd.py:66-68 prints and re-raises)."""
+    import os
+    if model_path is None:
+        raise ValueError("model_path is required")
+    if model_path.startswith("synthetic:"):
+        spec = model_path[len("synthetic:"):]
+        arch, _, q = spec.partition("?")
+        seed = 0
+        for kv in q.split("&"):
+            if kv.startswith("seed="):
+                seed = int(kv[5:])
+        if arch not in ARCHS:
+            raise ValueError(f"unknown architecture {arch!r}; known: {sorted(ARCHS)}")
+        net = ARCHS[arch](in_hw) if in_hw else ARCHS[arch]()
+        return net, synth_params(net, seed)
+    if not os.path.exists(model_path):
+        raise FileNotFoundError(f"model file not found: {model_path}")
+    if model_path.endswith(".npz"):
+        z = np.load(model_path, allow_pickle=False)
+        arch = str(z["__arch__"])
+        net = ARCHS[arch](in_hw) if in_hw else ARCHS[arch]()
+        return net, {k: z[k] for k in z.files if k != "__arch__"}
+    if model_path.endswith(".onnx"):
+        from .onnx_reader import load_onnx_params
+        base = os.path.splitext(os.path.basename(model_path))[0]
+        arch = ONNX_BASENAMES.get(base)
+        if arch is None:
+            raise ValueError(f"cannot tell the architecture of {model_path}; expected one of {sorted(ONNX_BASENAMES)}")
+        net = ARCHS[arch](in_hw) if in_hw else ARCHS[arch]()
+        return net, load_onnx_params(model_path, net)
+    raise ValueError(f"unsupported model file {model_path}")
+
+
+def save_params(path: str, arch: str, params: Dict[str, np.ndarray]):
+    np.savez(path, __arch__=np.array(arch), **params)
+
+
+class HeadViews:
+    """The 9 strided views fid_scrfd_postprocess reads (include/faceid.h)."""
+
+    def __init__(self, ptrs: Sequence[int], pix: Sequence[int], anc: Sequence[int], bstride: Sequence[int]):
+        self.ptrs = (C.c_void_p * 9)(*[C.c_void_p(int(p)) for p in ptrs])
+        self.pix = (C.c_int32 * 9)(*[int(v) for v in pix])
+        self.anc = (C.c_int32 * 9)(*[int(v) for v in anc])
+        self.bstride = (C.c_int64 * 9)(*[int(v) for v in bstride])
+
+    @staticmethod
+    def from_onnx_layout(bufs: Sequence[DeviceBuffer], A: int = 2):
+        """bufs: 9 device arrays [B, N_l, 1|4|10] in the ONNX output order (scores, bbox, kps)."""
+        ptrs, pix, anc, bs = [], [], [], []
+        for k, b in enumerate(bufs):
+            c = (1, 4, 10)[k // 3]
+            ptrs.append(b.ptr)
+            pix.append(A * c)
+            anc.append(c)
+            bs.append(b.shape[1] * c)
+        return HeadViews(ptrs, pix, anc, bs)
+
+    @staticmethod
+    def from_fused(cnet: CompiledNet):
+        """Views into the executor's fused fp32 head tensors [B, H, W, 32]."""
+        ptrs, pix, anc, bs = [None] * 9, [0] * 9, [0] * 9, [0] * 9
+        for li, name in enumerate(cnet.low.outputs):
+            h = cnet.low.heads[name]
+            base, (H, W, _, Cp), dt = cnet.tensor(name)
+            assert dt == np.float32
+            for part, (off, c) in enumerate((h["score"], h["bbox"], h["kps"])):
+                k = part * 3 + li
+                ptrs[k] = base + off * 4
+                pix[k] = Cp
+                anc[k] = c
+                bs[k] = H * W * Cp
+        return HeadViews(ptrs, pix, anc, bs)
+
+
+class PostProcessor:
+    """fid_scrfd_postprocess with persistent output buffers."""
+
+    def __init__(self, ctx: Context, max_batch: int, cap: int = 256, cand_cap: int = 4096):
+        self.ctx, self.cap, self.max_batch = ctx, int(cap), int(max_batch)
+        self.det = ctx.empty((max_batch, cap, 5), np.float32)
+        self.kps = ctx.empty((max_batch, cap, 10), np.float32)
+        self.counts = ctx.empty((max_batch,), np.int32)
+        self.cand_cap = int(cand_cap)
+        check(ctx.lib.fid_scrfd_set_candidate_capacity(ctx.handle, self.cand_cap))
+
+    def run(self, hv: HeadViews, B, in_hw, img_hw, conf, iou, max_num=0, metric=0, A=2):
+        assert B <= self.max_batch
+        check(self.ctx.lib.fid_scrfd_postprocess(
+            self.ctx.handle, C.cast(hv.ptrs, _lib.c_void_pp), hv.pix, hv.anc, hv.bstride, int(B), int(in_hw[0]),
+            int(in_hw[1]), int(A), int(img_hw[0]), int(img_hw[1]), float(conf), float(iou), int(max_num),
+            int(metric), C.c_void_p(self.det.ptr), C.c_void_p(self.kps.ptr), C.c_void_p(self.counts.ptr), self.cap))
+
+    def check(self) -> int:
+        m = C.c_int()
+        check(self.ctx.lib.fid_scrfd_check(self.ctx.handle, C.byref(m)))
+        return m.value
+
+    def fetch(self, B) -> List:
+        """[(det[K,5], kps[K,5,2])] per frame, host arrays (synchronises)."""
+        self.check()
+        counts = self.counts.download()[:B]
+        det = self.det.download()
+        kps = self.kps.download()
+        return [(det[b, :counts[b]].copy(), kps[b, :counts[b]].reshape(-1, 5, 2).copy()) for b in range(B)]
+
+
+class Gallery:
+    """fid_gallery: unit-length fp16 rows in HBM (what build_targets collects, reference main.py:78-105)."""
+
+    def __init__(self, ctx: Context, embeddings: np.ndarray, names: Optional[Sequence[str]] = None):
+        emb = np.ascontiguousarray(embeddings, dtype=np.float32)
+        assert emb.ndim == 2
+        self.ctx = ctx
+        self.G, self.dim = emb.shape
+        self.names = list(names) if names is not None else [str(i) for i in range(self.G)]
+        h = C.c_void_p()
+        check(ctx.lib.fid_gallery_create(ctx.handle, emb.ctypes.data_as(C.c_void_p), self.G, self.dim, C.byref(h)))
+        self.handle = h
+        gp = C.c_int()
+        check(ctx.lib.fid_gallery_info(h, None, C.byref(gp), None))
+        self.Gp = gp.value
+
+    def match_device(self, q_f16_dev, n, thresh, idx_dev, score_dev):
+        check(self.ctx.lib.fid_match(self.ctx.handle, self.handle, _lib._ptr(q_f16_dev), int(n), float(thresh),
+                                     _lib._ptr(idx_dev), _lib._ptr(score_dev)))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.fid_gallery_destroy(self.ctx.handle, self.handle)
+            self.handle = None

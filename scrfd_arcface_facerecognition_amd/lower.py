@@ -1,0 +1,310 @@
+"""Lowering: archs.Net + raw fp32 parameters  ->  the layer table libfaceid executes.
+
+This is the work onnxruntime's graph optimiser does invisibly inside InferenceSession (reference
+models/scrfd.py:59-62, models/arcface.py:18-21), written down:
+
+  * BatchNorm after a conv is folded into the conv's weights and bias;
+  * BatchNorm BEFORE a zero-padded conv (IResNet's bn1) is folded exactly: scale into the weights,
+    shift into a 9-entry border-class bias table (a border pixel's missing taps contribute no shift);
+  * AvgPool(2)+Conv1x1 ("avg_down" shortcut) becomes one 2x2/stride-2 conv with weights/4;
+  * nearest-2x upsample + add (PAFPN top-down) and the residual add become epilogue flags;
+  * the three SCRFD output convs of a level become one conv with 2+8+20 output channels, sigmoid on
+    the first two, bbox scale folded in, fp32 output;
+  * blobFromImage's (x-127.5)*scale and BGR->RGB swap are folded into the first conv's weights;
+  * FC consumes the NHWC activation directly (weight columns permuted from CHW order).
+
+Weights are packed fp16 [Cout_p][tap][Cin_p] (channels padded to multiples of 32 with zeros), all
+epilogue tables fp32.  Activation buffers are assigned to slots by liveness.
+Word layout of the op / tensor records: csrc/net.h.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .archs import BN_EPS, Net, infer_shapes
+
+OP_WORDS, TENSOR_WORDS = 32, 8
+OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV = 1, 2, 3, 4
+ACT = {"none": 0, "relu": 1, "prelu": 2}
+CF_RES_UP2, CF_BORDER, CF_OUT_F32 = 1, 2, 4
+CPAD = 32
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def _bn_affine(P, prefix):
+    a = P[prefix + ".gamma"].astype(np.float64) / np.sqrt(P[prefix + ".var"].astype(np.float64) + BN_EPS)
+    b = P[prefix + ".beta"].astype(np.float64) - P[prefix + ".mean"].astype(np.float64) * a
+    return a, b
+
+
+class _Blob:
+    def __init__(self):
+        self.parts: List[bytes] = []
+        self.size = 0
+
+    def add(self, arr: np.ndarray) -> Tuple[int, int]:
+        raw = np.ascontiguousarray(arr).tobytes()
+        off = self.size
+        pad = (-len(raw)) % 256
+        self.parts.append(raw + b"\0" * pad)
+        self.size += len(raw) + pad
+        return off, len(raw)
+
+    def bytes(self) -> bytes:
+        return b"".join(self.parts)
+
+
+class Lowered:
+    """Result of lower(): numpy tables + name maps."""
+
+    def __init__(self):
+        self.ops: np.ndarray = None          # int32 [n_ops, 32]
+        self.tensors: np.ndarray = None      # int32 [n_tensors, 8]
+        self.blob: bytes = b""
+        self.tensor_id: Dict[str, int] = {}
+        self.op_names: List[str] = []
+        self.outputs: List[str] = []
+        self.in_hw = (0, 0)
+        self.macs = 0
+        self.heads: Dict[str, dict] = {}     # DetHead name -> channel layout of the fused tensor
+
+
+def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
+    shp = infer_shapes(net)
+    blob = _Blob()
+    ops: List[List[int]] = []
+    op_names: List[str] = []
+    tensors: List[List[int]] = []
+    tid: Dict[str, int] = {}
+    out = Lowered()
+
+    def new_tensor(name, C, H, W, dtype=0, Cp=None):
+        Cp = _rup(C, CPAD) if Cp is None else Cp
+        tid[name] = len(tensors)
+        tensors.append([C, Cp, H, W, dtype, -1, 0, 0])
+        return tid[name]
+
+    def emit(name, **kw):
+        rec = [0] * OP_WORDS
+        rec[3] = -1
+        rec[13] = rec[15] = rec[16] = -1
+        rec[18] = 1
+        idx = dict(type=0, src=1, dst=2, res=3, kh=4, kw=5, stride=6, pad=7, cin=8, cout=9, act=10, flags=11,
+                   nsig=12, woff=13, wbytes=14, boff=15, soff=16, wrows=17, groups=18)
+        for k, v in kw.items():
+            rec[idx[k]] = int(v)
+        ops.append(rec)
+        op_names.append(name)
+
+    def pack_weights(W4, cin_p, cout_p):
+        """[cout, cin, kh, kw] float64 -> fp16 [cout_p][kh*kw][cin_p]"""
+        cout, cin, kh, kw = W4.shape
+        Wp = np.zeros((cout_p, kh * kw, cin_p), dtype=np.float32)
+        Wp[:cout, :, :cin] = W4.transpose(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+        h = Wp.astype(np.float16)
+        if not np.isfinite(h).all():
+            raise ValueError("weights overflow fp16")
+        return h
+
+    def padded(vec, n, fill=0.0):
+        o = np.full(n, fill, dtype=np.float32)
+        o[: len(vec)] = vec
+        return o
+
+    for n in net.nodes:
+        if n.kind == "conv" and n.src == "input":
+            assert n.k == 3 and n.pad == 1 and n.groups == 1 and not n.pre_bn and n.res is None
+            cout, (_, ho, wo) = n.cout, shp[n.name]
+            cp = _rup(cout, CPAD)
+            assert cp in (32, 64, 128), cp
+            W = P[n.wname + ".weight"].astype(np.float64)           # [cout, 3(RGB), 3, 3]
+            b = P[n.wname + ".bias"].astype(np.float64) if n.bias else np.zeros(cout)
+            if n.post_bn:
+                a2, b2 = _bn_affine(P, n.wname + ".post_bn")
+                W = W * a2[:, None, None, None]
+                b = b * a2 + b2
+            # kernel input is (2*pixel - 255) in BGR order: fold scale/2 and the channel swap
+            Wd = np.zeros((cp, 3, 3, 3), dtype=np.float32)            # [co][dy][dx][c_bgr]
+            Wd[:cout] = (W[:, ::-1] * (net.in_scale / 2.0)).transpose(0, 2, 3, 1)
+            assert abs(net.in_mean - 127.5) < 1e-12
+            woff, wbytes = blob.add(Wd)
+            boff, _ = blob.add(padded(b, cp))
+            soff = blob.add(padded(P[n.wname + ".prelu"], cp))[0] if n.act == "prelu" else -1
+            dst = new_tensor(n.name, cout, ho, wo)
+            emit(n.name, type=OP_STEM, src=-1, dst=dst, kh=3, kw=3, stride=n.stride, pad=1, cin=3, cout=cout,
+                 act=ACT[n.act], woff=woff, wbytes=wbytes, boff=boff, soff=soff, wrows=cp)
+        elif n.kind == "conv" and n.groups == 1:
+            cin, cout = n.cin, n.cout
+            _, ho, wo = shp[n.name]
+            src_t = tensors[tid[n.src]]
+            cin_p, cout_p = src_t[1], _rup(cout, CPAD)
+            W = P[n.wname + ".weight"].astype(np.float64)            # [cout, cin, k, k]
+            b = P[n.wname + ".bias"].astype(np.float64) if n.bias else np.zeros(cout)
+            k, stride, pad = n.k, n.stride, n.pad
+            if n.pre_avgpool:
+                assert k == 1 and pad == 0 and stride == 1
+                W = np.repeat(np.repeat(W, 2, axis=2), 2, axis=3) / 4.0
+                k, stride = 2, 2
+            ncls = 1
+            bias_tab = None
+            if n.pre_bn:
+                a1, b1 = _bn_affine(P, n.wname + ".pre_bn")
+                shift = np.einsum("oikl,i->okl", W, b1)                # per-tap contribution of the BN shift
+                W = W * a1[None, :, None, None]
+                if pad == 0:
+                    b = b + shift.sum(axis=(1, 2))
+                else:
+                    assert k == 3 and pad == 1 and stride == 1 and src_t[2] >= 2 and src_t[3] >= 2, n.name
+                    ncls = 9
+                    bias_tab = np.zeros((9, cout))
+                    for yc in range(3):
+                        for xc in range(3):
+                            m = np.ones((3, 3))
+                            if yc == 0: m[0, :] = 0
+                            if yc == 2: m[2, :] = 0
+                            if xc == 0: m[:, 0] = 0
+                            if xc == 2: m[:, 2] = 0
+                            bias_tab[yc * 3 + xc] = b + (shift * m[None]).sum(axis=(1, 2))
+            if bias_tab is None:
+                bias_tab = b[None, :]
+            if n.post_bn:
+                a2, b2 = _bn_affine(P, n.wname + ".post_bn")
+                W = W * a2[:, None, None, None]
+                bias_tab = bias_tab * a2[None, :] + b2[None, :]
+            Wp = pack_weights(W, cin_p, cout_p)
+            woff, wbytes = blob.add(Wp)
+            bt = np.zeros((ncls, cout_p), dtype=np.float32)
+            bt[:, :cout] = bias_tab
+            boff, _ = blob.add(bt)
+            soff = blob.add(padded(P[n.wname + ".prelu"], cout_p))[0] if n.act == "prelu" else -1
+            flags = (CF_BORDER if ncls == 9 else 0) | (CF_RES_UP2 if n.res_up2 else 0)
+            dst = new_tensor(n.name, cout, ho, wo)
+            emit(n.name, type=OP_CONV, src=tid[n.src], dst=dst, res=tid[n.res] if n.res else -1, kh=k, kw=k,
+                 stride=stride, pad=pad, cin=cin, cout=cout, act=ACT[n.act], flags=flags, woff=woff,
+                 wbytes=wbytes, boff=boff, soff=soff, wrows=cout_p)
+        elif n.kind == "conv":                                        # depthwise
+            assert n.groups == n.cin == n.cout and not n.pre_bn and not n.pre_avgpool and n.res is None
+            c = n.cin
+            _, ho, wo = shp[n.name]
+            cp = tensors[tid[n.src]][1]
+            W = P[n.wname + ".weight"].astype(np.float64)[:, 0]       # [c, k, k]
+            b = P[n.wname + ".bias"].astype(np.float64) if n.bias else np.zeros(c)
+            if n.post_bn:
+                a2, b2 = _bn_affine(P, n.wname + ".post_bn")
+                W = W * a2[:, None, None]
+                b = b * a2 + b2
+            Wd = np.zeros((n.k * n.k, cp), dtype=np.float32)
+            Wd[:, :c] = W.reshape(c, -1).T
+            woff, wbytes = blob.add(Wd)
+            boff, _ = blob.add(padded(b, cp))
+            soff = blob.add(padded(P[n.wname + ".prelu"], cp))[0] if n.act == "prelu" else -1
+            dst = new_tensor(n.name, c, ho, wo, Cp=cp)
+            emit(n.name, type=OP_DWCONV, src=tid[n.src], dst=dst, kh=n.k, kw=n.k, stride=n.stride, pad=n.pad,
+                 cin=c, cout=c, act=ACT[n.act], woff=woff, wbytes=wbytes, boff=boff, soff=soff, wrows=cp, groups=c)
+        elif n.kind == "maxpool":
+            c, ho, wo = shp[n.name]
+            dst = new_tensor(n.name, c, ho, wo, Cp=tensors[tid[n.src]][1])
+            emit(n.name, type=OP_MAXPOOL, src=tid[n.src], dst=dst, kh=n.k, kw=n.k, stride=n.stride, pad=n.pad,
+                 cin=c, cout=c)
+        elif n.kind == "fc":
+            src_t = tensors[tid[n.src]]
+            C_, Cp_, H_, W_ = src_t[0], src_t[1], src_t[2], src_t[3]
+            assert (C_, H_, W_) == (n.c, n.h, n.w)
+            Wm = P[n.wname + ".weight"].astype(np.float64).reshape(n.cout, n.c, n.h, n.w)
+            b = P[n.wname + ".bias"].astype(np.float64) if n.bias else np.zeros(n.cout)
+            if n.pre_bn:
+                a1, b1 = _bn_affine(P, n.wname + ".pre_bn")
+                b = b + np.einsum("ochw,c->o", Wm, b1)
+                Wm = Wm * a1[None, :, None, None]
+            if n.post_bn:
+                a2, b2 = _bn_affine(P, n.wname + ".post_bn")
+                Wm = Wm * a2[:, None, None, None]
+                b = b * a2 + b2
+            K = H_ * W_ * Cp_
+            cout_p = _rup(n.cout, CPAD)
+            Wk = np.zeros((cout_p, H_, W_, Cp_), dtype=np.float32)     # NHWC flatten order of the activation
+            Wk[: n.cout, :, :, : n.c] = Wm.transpose(0, 2, 3, 1)
+            h = Wk.reshape(cout_p, 1, K).astype(np.float16)
+            woff, wbytes = blob.add(h)
+            boff, _ = blob.add(padded(b, cout_p)[None, :])
+            view = new_tensor(n.name + ".in_view", K, 1, 1, Cp=K)     # alias of the source tensor
+            tensors[view][5] = -2 - tid[n.src]                        # resolved to the source's slot below
+            dst = new_tensor(n.name, n.cout, 1, 1, dtype=1)
+            emit(n.name, type=OP_CONV, src=view, dst=dst, kh=1, kw=1, stride=1, pad=0, cin=n.c * n.h * n.w,
+                 cout=n.cout, act=0, flags=0, woff=woff, wbytes=wbytes, boff=boff, wrows=cout_p)
+        elif n.kind == "dethead":
+            A = n.num_anchors
+            _, h_, w_ = shp[n.name]
+            src_t = tensors[tid[n.src]]
+            s = float(P[n.wname + ".bbox.scale"][0])
+            W = np.concatenate([P[n.wname + ".cls.weight"], P[n.wname + ".bbox.weight"] * s,
+                                P[n.wname + ".kps.weight"]], axis=0).astype(np.float64)
+            b = np.concatenate([P[n.wname + ".cls.bias"], P[n.wname + ".bbox.bias"] * s,
+                                P[n.wname + ".kps.bias"]]).astype(np.float64)
+            cout = 15 * A
+            cout_p = _rup(cout, CPAD)
+            Wp = pack_weights(W, src_t[1], cout_p)
+            woff, wbytes = blob.add(Wp)
+            boff, _ = blob.add(padded(b, cout_p)[None, :])
+            dst = new_tensor(n.name, cout, h_, w_, dtype=1)
+            emit(n.name, type=OP_CONV, src=tid[n.src], dst=dst, kh=n.k, kw=n.k, stride=1, pad=n.k // 2, cin=n.cin,
+                 cout=cout, act=0, flags=0, nsig=A, woff=woff, wbytes=wbytes, boff=boff, wrows=cout_p)
+            out.heads[n.name] = dict(stride=n.stride, anchors=A, cp=cout_p, h=h_, w=w_,
+                                     score=(0, 1), bbox=(A, 4), kps=(5 * A, 10))
+        else:
+            raise ValueError(f"cannot lower node {n}")
+
+    # ---- liveness-based slot assignment -------------------------------------------------------
+    n_t = len(tensors)
+    base = list(range(n_t))                       # alias -> base tensor
+    for t in range(n_t):
+        if tensors[t][5] <= -2:
+            base[t] = -2 - tensors[t][5]
+    last_use = [-1] * n_t
+    for oi, rec in enumerate(ops):
+        for w in (1, 3):
+            if rec[w] >= 0:
+                last_use[base[rec[w]]] = oi
+    keep = {tid[o] for o in net.outputs}
+    slot_of = [-1] * n_t
+    slot_size: List[int] = []
+    free: List[int] = []
+
+    def nbytes(t):
+        return tensors[t][1] * tensors[t][2] * tensors[t][3] * (4 if tensors[t][4] == 1 else 2)
+
+    for oi, rec in enumerate(ops):
+        d = rec[2]
+        need = nbytes(d)
+        if d in keep or not free:
+            slot_size.append(need)
+            slot_of[d] = len(slot_size) - 1
+        else:
+            best = min(free, key=lambda s: (slot_size[s] < need, abs(slot_size[s] - need)))
+            free.remove(best)
+            slot_size[best] = max(slot_size[best], need)
+            slot_of[d] = best
+        for t in range(n_t):
+            if base[t] == t and slot_of[t] >= 0 and last_use[t] == oi and t not in keep and t != d:
+                free.append(slot_of[t])
+        if last_use[d] < 0 and d not in keep:      # produced but never read
+            free.append(slot_of[d])
+    for t in range(n_t):
+        tensors[t][5] = slot_of[base[t]]
+        if t in keep:
+            tensors[t][6] = 1
+        assert tensors[t][5] >= 0, t
+
+    out.ops = np.asarray(ops, dtype=np.int32).reshape(-1, OP_WORDS)
+    out.tensors = np.asarray(tensors, dtype=np.int32).reshape(-1, TENSOR_WORDS)
+    out.blob = blob.bytes()
+    out.tensor_id = tid
+    out.op_names = op_names
+    out.outputs = list(net.outputs)
+    out.in_hw = net.in_hw
+    return out

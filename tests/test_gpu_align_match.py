@@ -1,0 +1,147 @@
+"""GPU parity: alignment (Umeyama + fixed-point warp, letterbox resize) and gallery match."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import align, match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from scrfd_arcface_facerecognition_amd._lib import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def align_on_gpu(ctx, frames, kps, counts, F):
+    from scrfd_arcface_facerecognition_amd._lib import check
+    B, H, W, _ = frames.shape
+    cap = kps.shape[1]
+    fr, kp, cn = ctx.to_device(frames), ctx.to_device(kps.astype(np.float32)), ctx.to_device(counts.astype(np.int32))
+    crops = ctx.empty((B * F, 112, 112, 3), np.uint8)
+    M = ctx.empty((B * F, 6), np.float64)
+    check(ctx.lib.fid_align_crops(ctx.handle, C.c_void_p(fr.ptr), B, H, W, C.c_void_p(kp.ptr), C.c_void_p(cn.ptr), cap, F,
+                                  C.c_void_p(crops.ptr), C.c_void_p(M.ptr)))
+    return crops.download(), M.download().reshape(B * F, 2, 3)
+
+
+def test_estimate_norm_vs_skimage_goldens(ctx):
+    g = load_golden("umeyama.npz")
+    lms = g["landmarks"]
+    n = len(lms)
+    frames = np.zeros((1, 8, 8, 3), np.uint8)
+    _, M = align_on_gpu(ctx, frames, lms.reshape(1, n, 10), np.array([n]), n)
+    for i in range(n):
+        scale = max(1.0, np.abs(g["M"][i]).max())
+        assert np.abs(M[i] - g["M"][i]).max() / scale < 1e-5, i       # SURVEY.md A.2 tolerance (skimage runs fp32 SVD)
+        m64, _ = align.estimate_norm(lms[i], f64=True)                # same closed form in fp64: ~1e-12
+        assert np.abs(M[i] - m64).max() / scale < 1e-9, i
+
+
+def test_warp_bit_exact_vs_oracle(ctx):
+    rng = np.random.default_rng(3)
+    B, H, W, F = 3, 360, 480, 4
+    frames = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    tmpl = align.REFERENCE_ALIGNMENT[0].astype(np.float64)
+    kps = np.zeros((B, F, 10), np.float32)
+    for b in range(B):
+        for f in range(F):
+            s, th = rng.uniform(0.4, 3.0), rng.uniform(-1.0, 1.0)
+            R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+            t = np.array([rng.uniform(-40, W + 40), rng.uniform(-40, H + 40)])   # some faces hang over the border
+            kps[b, f] = ((tmpl - 56) @ R.T * s + t + rng.normal(0, 1.0, (5, 2))).reshape(-1)
+    counts = np.array([4, 2, 0])
+    crops, M = align_on_gpu(ctx, frames, kps, counts, F)
+    crops = crops.reshape(B, F, 112, 112, 3)
+    for b in range(B):
+        for f in range(F):
+            if f < counts[b]:
+                ref = align.norm_crop_image(frames[b], kps[b, f].reshape(5, 2))
+                assert np.array_equal(crops[b, f], ref), (b, f)
+                assert ref.max() > 0
+            else:
+                assert not crops[b, f].any()
+
+
+@pytest.mark.parametrize("shape", [(1080, 1920), (480, 853), (1280, 1280), (640, 640), (700, 500)])
+def test_letterbox_bit_exact_vs_oracle(ctx, shape):
+    from scrfd_arcface_facerecognition_amd._lib import check
+    rng = np.random.default_rng(5)
+    H, W = shape
+    frames = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    fr = ctx.to_device(frames)
+    out = ctx.empty((2, 640, 640, 3), np.uint8)
+    sc = C.c_double()
+    check(ctx.lib.fid_letterbox(ctx.handle, C.c_void_p(fr.ptr), 2, H, W, C.c_void_p(out.ptr), 640, 640, C.byref(sc)))
+    got = out.download()
+    for b in range(2):
+        ref, scale = align.letterbox(frames[b])
+        assert scale == sc.value
+        assert np.array_equal(got[b], ref), shape
+
+
+def gpu_match(ctx, emb, gallery, thr):
+    from scrfd_arcface_facerecognition_amd._lib import check
+    from scrfd_arcface_facerecognition_amd.engine import Gallery
+    gal = Gallery(ctx, gallery)
+    n, dim = emb.shape
+    e = ctx.to_device(emb.astype(np.float32))
+    q = ctx.empty((n, dim), np.float16)
+    check(ctx.lib.fid_l2_normalize_f16(ctx.handle, C.c_void_p(e.ptr), n, dim, C.c_void_p(q.ptr)))
+    idx, sc = ctx.empty((n,), np.int32), ctx.empty((n,), np.float32)
+    gal.match_device(q, n, thr, idx, sc)
+    cm = ctx.empty((n, gal.Gp), np.float32)
+    check(ctx.lib.fid_cosine_matrix(ctx.handle, gal.handle, C.c_void_p(q.ptr), n, C.c_void_p(cm.ptr)))
+    res = idx.download(), sc.download(), cm.download()[:, :gal.G]
+    gal.close()
+    return res
+
+
+def test_gallery_scan_goldens(ctx):
+    g = load_golden("gallery_scan.npz")
+    for thr in g["thrs"]:
+        idx, sc, cm = gpu_match(ctx, g["emb"], g["gallery"], float(thr))
+        ref_idx, ref_sim = g[f"idx_thr{thr}"], g[f"sim_thr{thr}"]
+        e = g["emb"] / np.linalg.norm(g["emb"], axis=1, keepdims=True)
+        gg = g["gallery"] / np.linalg.norm(g["gallery"], axis=1, keepdims=True)
+        true = e @ gg.T
+        for i in range(len(idx)):
+            if idx[i] != ref_idx[i]:
+                # fp16 unit vectors: only entries whose true cosine is within 1e-3 of the winner
+                # (rows 3/4 are deliberate twins) or of the threshold may be swapped
+                if idx[i] >= 0 and ref_idx[i] >= 0:
+                    assert abs(true[i, idx[i]] - true[i, ref_idx[i]]) < 1e-3, (thr, i)
+                else:
+                    assert abs(true[i].max() - max(float(thr), 0.0)) < 1e-3, (thr, i)
+                continue
+            assert abs(sc[i] - ref_sim[i]) < 1e-3, (thr, i)        # north_star tolerance for cosine in fp16
+
+
+def test_cosine_matrix_within_1e3(ctx):
+    g = load_golden("cosine.npz")
+    _, _, cm = gpu_match(ctx, g["a"], g["b"], 0.0)
+    got = np.diag(cm)
+    ok = np.isfinite(g["sim"])
+    assert np.abs(got[ok] - g["sim"][ok]).max() < 1e-3
+
+
+@pytest.mark.parametrize("n,G", [(1, 5), (64, 1000), (300, 4097), (7, 33)])
+def test_match_random_vs_oracle(ctx, n, G):
+    rng = np.random.default_rng(n * 1000 + G)
+    gallery = rng.standard_normal((G, 512)).astype(np.float32)
+    emb = rng.standard_normal((n, 512)).astype(np.float32)
+    for i in range(0, n, 2):       # half of the queries are noisy copies of a gallery row
+        emb[i] = gallery[rng.integers(0, G)] + 0.7 * rng.standard_normal(512).astype(np.float32)
+    idx, sc, cm = gpu_match(ctx, emb, gallery, 0.4)
+    oi, osim = match.match_batch(emb, gallery, 0.4)
+    e = emb / np.linalg.norm(emb, axis=1, keepdims=True)
+    gg = gallery / np.linalg.norm(gallery, axis=1, keepdims=True)
+    assert np.abs(cm - e @ gg.T).max() < 1e-3
+    margin = np.abs(np.sort(e @ gg.T, axis=1)[:, -1] - 0.4) > 2e-3     # decisions not within fp16 noise of the threshold
+    assert np.array_equal(idx[margin], oi[margin])
+    assert np.abs(sc[margin] - osim[margin]).max() < 1e-3

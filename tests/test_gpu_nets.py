@@ -1,0 +1,150 @@
+"""GPU parity: the conv-net executor (MFMA implicit-GEMM conv, stem, pooling, depthwise, FC,
+BN folding / fusion done by lower.py) against the fp32 torch-CPU oracle on identical weights.
+Tolerances: activations are fp16 on the GPU (fp32 accumulate), so intermediate tensors are compared
+relative to their own scale; embeddings by cosine (north_star: within 1e-3)."""
+import numpy as np
+import pytest
+
+from oracle import align, nets as onets
+from scrfd_arcface_facerecognition_amd import archs
+from scrfd_arcface_facerecognition_amd.archs import Conv, DetHead, FC, MaxPool, Net
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from scrfd_arcface_facerecognition_amd._lib import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def run_both(ctx, net, P, images, names):
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    cn = CompiledNet(ctx, net, P, max_batch=len(images))
+    cn.run(images)
+    got = {k: cn.read(k, len(images)) for k in names}
+    blob = align.blob_from_images(list(images), net.in_scale, net.in_mean)
+    ref = onets.run_net(net, P, blob, keep=names)
+    cn.close()
+    return got, ref
+
+
+def rel_err(got_nhwc, ref_nchw):
+    ref = np.transpose(ref_nchw, (0, 2, 3, 1))
+    return float(np.abs(got_nhwc - ref).max() / (np.abs(ref).max() + 1e-6))
+
+
+def small_net(hw, body):
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    body(net)
+    return net
+
+
+CASES = {
+    "3x3_s1_c64": lambda n: (n.add(Conv("s", "input", 3, 64, act="relu")), n.add(Conv("c", "s", 64, 64, act="relu"))),
+    "3x3_s2_c64_128": lambda n: (n.add(Conv("s", "input", 3, 64, act="prelu")), n.add(Conv("c", "s", 64, 128, stride=2, act="prelu"))),
+    "1x1_s2_down": lambda n: (n.add(Conv("s", "input", 3, 64, act="relu")), n.add(Conv("c", "s", 64, 128, k=1, stride=2, pad=0))),
+    "odd_channels_28_56_88": lambda n: (n.add(Conv("s", "input", 3, 28, stride=2, act="relu")), n.add(Conv("a", "s", 28, 56, act="relu")),
+                                         n.add(Conv("c", "a", 56, 88, stride=2, act="relu"))),
+    "avg_down": lambda n: (n.add(Conv("s", "input", 3, 56, act="relu")), n.add(Conv("c", "s", 56, 88, k=1, pad=0, pre_avgpool=True))),
+    "prebn_border_residual": lambda n: (n.add(Conv("s", "input", 3, 64, act="prelu")),
+                                         n.add(Conv("a", "s", 64, 64, pre_bn=True, act="prelu")),
+                                         n.add(Conv("c", "a", 64, 64, res="s"))),
+    "fpn_up2_add": lambda n: (n.add(Conv("s0", "input", 3, 64, stride=2, act="relu")), n.add(Conv("s", "s0", 64, 88, k=1, pad=0, act="relu")),
+                              n.add(Conv("d", "s", 88, 224, stride=2, act="relu")),
+                              n.add(Conv("l2", "d", 224, 56, k=1, pad=0, bias=True, post_bn=False)),
+                              n.add(Conv("c", "s", 88, 56, k=1, pad=0, bias=True, post_bn=False, res="l2", res_up2=True))),
+    "maxpool": lambda n: (n.add(Conv("s", "input", 3, 56, stride=2, act="relu")), n.add(MaxPool("c", "s", 56))),
+    "depthwise": lambda n: (n.add(Conv("s", "input", 3, 128, stride=2, act="prelu")), n.add(Conv("d", "s", 128, 128, groups=128, act="prelu")),
+                            n.add(Conv("c", "d", 128, 128, groups=128, stride=2, act="relu"))),
+    "wide_256_512": lambda n: (n.add(Conv("s", "input", 3, 64, stride=2, act="relu")), n.add(Conv("a", "s", 64, 256, stride=2, act="relu")),
+                               n.add(Conv("c", "a", 256, 512, stride=2, act="prelu"))),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("hw,batch", [((32, 48), 3), ((64, 64), 2)])
+def test_layer_cases(ctx, case, hw, batch):
+    net = small_net(hw, CASES[case])
+    net.outputs = ["c"]
+    P = archs.synth_params(net, seed=1)
+    rng = np.random.default_rng(7)
+    images = rng.integers(0, 256, (batch, hw[0], hw[1], 3), dtype=np.uint8)
+    got, ref = run_both(ctx, net, P, images, ["s", "c"])
+    assert rel_err(got["s"], ref["s"]) < 3e-3          # stem: exact inputs, fp32 math, fp16 store
+    assert rel_err(got["c"], ref["c"]) < 6e-3, case
+
+
+def test_dethead_and_fc(ctx):
+    net = Net("t", (64, 64), 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 56, stride=2, act="relu"))
+    net.add(Conv("t0", "s", 56, 80, act="relu"))
+    net.add(DetHead("h", "t0", 80, 8))
+    net.add(Conv("d", "s", 56, 512, stride=2, k=3, act="none"))
+    net.add(Conv("e", "d", 512, 512, stride=2, k=3, act="none"))
+    net.add(FC("fc", "e", 512, 8, 8, 512))
+    net.outputs = ["h", "fc"]
+    P = archs.synth_params(net, seed=2)
+    images = np.random.default_rng(1).integers(0, 256, (2, 64, 64, 3), dtype=np.uint8)
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    cn = CompiledNet(ctx, net, P, max_batch=2)
+    cn.run(images)
+    fused = cn.read("h", 2)                              # [B,H,W,30]: cls(2) bbox(8) kps(20)
+    emb = cn.read("fc", 2).reshape(2, 512)
+    cn.close()
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))
+    sc, bb, kp = ref["h"]
+    B = 2
+    assert np.abs(fused[..., 0:2].reshape(B, -1, 1) - sc).max() < 2e-3
+    assert np.abs(fused[..., 2:10].reshape(B, -1, 4) - bb).max() < 2e-2
+    assert np.abs(fused[..., 10:30].reshape(B, -1, 10) - kp).max() < 2e-2
+    assert np.abs(emb - ref["fc"]).max() / np.abs(ref["fc"]).max() < 5e-3
+
+
+def cosine(a, b):
+    return float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def test_arcface_r50_embeddings(ctx):
+    net = archs.iresnet50()
+    P = archs.synth_params(net, seed=0)
+    rng = np.random.default_rng(11)
+    images = rng.integers(0, 256, (3, 112, 112, 3), dtype=np.uint8)
+    got, ref = run_both(ctx, net, P, images, ["fc"])
+    e, r = got["fc"].reshape(3, 512), ref["fc"].reshape(3, 512)
+    for i in range(3):
+        assert 1.0 - cosine(e[i], r[i]) < 1e-3, i
+        en, rn = e[i] / np.linalg.norm(e[i]), r[i] / np.linalg.norm(r[i])
+        assert np.abs(en - rn).max() < 1e-3, i          # unit-embedding components within 1e-3
+    # different faces must stay different (not a degenerate net)
+    assert cosine(r[0], r[1]) < 0.999
+
+
+def test_arcface_mbf_embeddings(ctx):
+    net = archs.mobilefacenet()
+    P = archs.synth_params(net, seed=0)
+    images = np.random.default_rng(12).integers(0, 256, (2, 112, 112, 3), dtype=np.uint8)
+    got, ref = run_both(ctx, net, P, images, ["fc"])
+    e, r = got["fc"].reshape(2, 512), ref["fc"].reshape(2, 512)
+    for i in range(2):
+        assert 1.0 - cosine(e[i], r[i]) < 1e-3
+
+
+@pytest.mark.parametrize("arch", ["scrfd_10g", "scrfd_2.5g", "scrfd_500m"])
+def test_scrfd_heads(ctx, arch):
+    net = archs.ARCHS[arch]((320, 320))
+    P = archs.synth_params(net, seed=0)
+    images = np.random.default_rng(13).integers(0, 256, (1, 320, 320, 3), dtype=np.uint8)
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    cn = CompiledNet(ctx, net, P, max_batch=1)
+    cn.run(images)
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))
+    for name in net.outputs:
+        fused = cn.read(name, 1)
+        sc, bb, kp = ref[name]
+        assert np.abs(fused[..., 0:2].reshape(1, -1, 1) - sc).max() < 3e-3, name       # sigmoid scores
+        assert np.abs(fused[..., 2:10].reshape(1, -1, 4) - bb).max() < 3e-2, name      # stride units
+        assert np.abs(fused[..., 10:30].reshape(1, -1, 10) - kp).max() < 3e-2, name
+    cn.close()
