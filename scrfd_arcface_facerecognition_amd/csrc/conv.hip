@@ -337,6 +337,16 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
         int want = (int)((2LL * num_cus + t - 1) / t);
         p.ksplit = std::max(1, std::min(want, ksteps / 4));
     }
+    // experiment hook (tools/conv_sweep.py): FID_CONV_FORCE="bm,bn,ksplit" overrides the heuristic
+    if (const char *f = getenv("FID_CONV_FORCE")) {
+        int bm = 0, bn = 0, ks = 0;
+        if (sscanf(f, "%d,%d,%d", &bm, &bn, &ks) == 3) {
+            const bool have = p.bk == 64 ? ((bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64))
+                                         : (bm == 128 && (bn == 128 || bn == 64 || bn == 32));
+            if (have) { p.bm = bm; p.bn = bn; }
+            if (ks >= 1 && allow_split && !(a.flags & CF_ARGMAX)) p.ksplit = std::max(1, std::min(ks, ksteps / 2));
+        }
+    }
     p.partial_bytes = p.ksplit > 1 ? (size_t)p.ksplit * a.M * a.Cout_p * 4 : 0;
     return p;
 }
