@@ -24,3 +24,22 @@ def test_library_exports_every_declared_symbol():
 
 def test_device_count_call_is_safe_without_gpu():
     assert _lib.device_count() >= 0
+
+
+def test_product_does_not_import_oracle():
+    """oracle/ is test infrastructure: nothing under the product package (or the drop-in shims) may use it."""
+    import glob
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle)", re.M)
+    files = glob.glob(os.path.join(ROOT, "scrfd_arcface_facerecognition_amd", "**", "*.py"), recursive=True)
+    files += glob.glob(os.path.join(ROOT, "models", "*.py")) + glob.glob(os.path.join(ROOT, "utils", "*.py"))
+    assert len(files) > 8
+    for f in files:
+        assert not pat.search(open(f).read()), f
+
+
+def test_library_missing_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        _lib.load()
