@@ -79,6 +79,9 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
                    int max_batch, fid_net **out);
 int fid_net_destroy(fid_ctx *ctx, fid_net *net);
 int fid_net_run(fid_ctx *ctx, fid_net *net, const uint8_t *images_dev, int batch);
+/* Execute depth-first over sub-batches of this many images (0 = the whole batch layer by layer), so
+ * that a layer's input is still in L2 / Infinity Cache when the next layer reads it. */
+int fid_net_set_sub_batch(fid_net *net, int sub_batch);
 /* device address + geometry of a tensor of the last run: dims = {H, W, C_logical, C_stored},
  * dtype 0 = fp16, 1 = fp32; layout [batch, H, W, C_stored]. */
 int fid_net_tensor(fid_net *net, int tensor_id, void **dptr, int dims[4], int *dtype);

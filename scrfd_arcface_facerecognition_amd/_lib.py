@@ -39,6 +39,7 @@ SIGNATURES = {
                                  C.c_int, C.c_int, C.c_int, c_void_pp]),
     "fid_net_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fid_net_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "fid_net_set_sub_batch": (C.c_int, [C.c_void_p, C.c_int]),
     "fid_net_tensor": (C.c_int, [C.c_void_p, C.c_int, c_void_pp, c_int_p, c_int_p]),
     "fid_net_run_profiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_f32_p]),
     "fid_net_macs": (C.c_int, [C.c_void_p, c_f64_p]),

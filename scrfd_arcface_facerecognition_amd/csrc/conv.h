@@ -39,4 +39,8 @@ struct ConvPlan {
 ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split);
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan);
 
+// conv_direct.hip: 3x3/s1 conv with LDS-resident weights + haloed patches (<= 64 channels in and out)
+bool conv_direct_applicable(const ConvArgs &a);
+int conv_direct_launch(fid_ctx *ctx, const ConvArgs &a);
+
 }  // namespace fid

@@ -23,7 +23,7 @@
 // the exact fold of a BatchNorm that sits in front of a zero-padded conv), + residual (optionally
 // nearest-2x upsampled), ReLU / PReLU, sigmoid on the first nsig channels, fp16 or fp32 store;
 // or split-K partial slabs; or arg-max over columns.
-#include "conv.h"
+#include "epilogue.h"
 
 namespace fid {
 namespace {
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
     constexpr int RPP = 256 / CPR;  // rows staged per pass of the 256 threads
     constexpr int A_LD = BM / RPP, B_LD = (BN + RPP - 1) / RPP;
     constexpr bool B_PARTIAL = (BN % RPP) != 0;  // fewer weight rows than one staging pass (BN=32, BK=32)
-    static_assert(WM * WN == 4 && BM % RPP == 0 && (BN % RPP == 0 || BN < RPP) && MI >= 1 && NI >= 1, "tile shape");
+    static_assert(WM * WN == 4 && BM % RPP == 0 && TN % 16 == 0 && TM % 16 == 0 && MI >= 1 && NI >= 1, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16 *sA = (_Float16 *)smem;            // [2][BM][BK] pixels
     _Float16 *sB = sA + 2 * BM * BK;            // [2][BN][BK] weights
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < B_LD; i++) {
         const int co = tn * BN + i * RPP + lrow;
-        b_off[i] = (co < a.w_rows && (!B_PARTIAL || lrow < BN)) ? co * a.T * a.Cin_p + lch * 8 : -1;
+        b_off[i] = (co < a.w_rows && (!B_PARTIAL || i * RPP + lrow < BN)) ? co * a.T * a.Cin_p + lch * 8 : -1;
     }
 
     const int ks_begin = split * a.ksteps_per_split;
@@ -268,23 +268,37 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
         }
         return;
     }
+    if (a.ksplit > 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            const int m = tm * BM + wm * TM + mi * 16 + frow;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int co0 = tn * BN + wn * TN + ni * 16 + fq * 4;
+                if (co0 < a.Cout_p) *(f32x4 *)(a.partial + ((size_t)split * a.M + m) * a.Cout_p + co0) = acc[ni][mi];
+            }
+        }
+        return;
+    }
     const bool need_pix = (a.flags & (CF_BORDER | CF_RES_UP2)) != 0;
+    EpiArgs ep{a.bias, a.slope, a.res, a.out, a.Cout_p, a.Ho, a.Wo, a.act, a.flags, a.nsig, a.res_H, a.res_W, a.res_Cp};
+    EpiPix px[MI];
+    int co0[NI];
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
         const int m = tm * BM + wm * TM + mi * 16 + frow;
-        if (m >= a.M) continue;
-        Pix p{0, 0, 0};
-        if (need_pix) p = decompose(a, m);
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++) {
-            const int co0 = tn * BN + wn * TN + ni * 16 + fq * 4;
-            if (co0 >= a.Cout_p) continue;
-            if (a.ksplit > 1)
-                *(f32x4 *)(a.partial + ((size_t)split * a.M + m) * a.Cout_p + co0) = acc[ni][mi];
-            else
-                epilogue4(a, m, co0, acc[ni][mi], p);
+        px[mi].valid = m < a.M;
+        px[mi].m = px[mi].valid ? m : 0;
+        px[mi].n = px[mi].oy = px[mi].ox = 0;
+        if (need_pix && px[mi].valid) {
+            const Pix p = decompose(a, m);
+            px[mi].n = p.n; px[mi].oy = p.oy; px[mi].ox = p.ox;
         }
     }
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) co0[ni] = tn * BN + wn * TN + ni * 16 + fq * 4;
+    epilogue_tile<NI, MI>(ep, acc, px, co0);
 }
 
 // second pass of a split-K conv: sum the slabs in a fixed order (bit-reproducible), then the epilogue
@@ -327,7 +341,8 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
         if (tiles(p.bm, p.bn) < 2LL * num_cus) p.bm = 64, p.bn = 64;
     } else {
         p.bm = 128;
-        p.bn = a.Cout_p >= 128 ? 128 : (a.Cout_p > 32 ? 64 : 32);
+        p.bn = a.Cout_p >= 128 ? 128 : (a.Cout_p > 64 ? 96 : (a.Cout_p > 32 ? 64 : 32));
+        if (a.Cout_p % 96 == 0 && a.Cout_p % 128 != 0) p.bn = 96;      // 96 / 288-wide layers: no half-empty column tile
         auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
         if (tiles(p.bm, p.bn) < 2LL * num_cus && p.bn == 128) p.bn = 64;
     }
@@ -342,7 +357,7 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
         int bm = 0, bn = 0, ks = 0;
         if (sscanf(f, "%d,%d,%d", &bm, &bn, &ks) == 3) {
             const bool have = p.bk == 64 ? ((bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64))
-                                         : (bm == 128 && (bn == 128 || bn == 64 || bn == 32));
+                                         : (bm == 128 && (bn == 128 || bn == 96 || bn == 64 || bn == 32));
             if (have) { p.bm = bm; p.bn = bn; }
             if (ks >= 1 && allow_split && !(a.flags & CF_ARGMAX)) p.ksplit = std::max(1, std::min(ks, ksteps / 2));
         }
@@ -371,6 +386,7 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
         case 128064064: rc = launch_cfg<128, 64, 64, 2, 2>(ctx, a); break;
         case 64064064: rc = launch_cfg<64, 64, 64, 2, 2>(ctx, a); break;
         case 128128032: rc = launch_cfg<128, 128, 32, 2, 2>(ctx, a); break;
+        case 128096032: rc = launch_cfg<128, 96, 32, 2, 2>(ctx, a); break;
         case 128064032: rc = launch_cfg<128, 64, 32, 2, 2>(ctx, a); break;
         case 128032032: rc = launch_cfg<128, 32, 32, 4, 1>(ctx, a); break;
         default: set_error("conv: no kernel for tile %dx%dx%d", plan.bm, plan.bn, plan.bk); return FID_E_INVALID;

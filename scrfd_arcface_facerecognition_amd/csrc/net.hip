@@ -16,6 +16,7 @@ struct fid_net {
     std::vector<void *> slots;
     std::vector<size_t> slot_bytes_per_image;
     double macs_per_image = 0;
+    int sub_batch = 0;   // images per depth-first pass (0 = whole batch)
     hipEvent_t *prof_events = nullptr;
     int n_prof_events = 0;
 };
@@ -149,15 +150,18 @@ struct TensorView {
     int C, Cp, H, W, dtype;
 };
 
-TensorView view(const fid_net *net, int id) {
+TensorView view(const fid_net *net, int id, int first = 0) {
     const int32_t *t = &net->tensors[(size_t)id * FID_TENSOR_WORDS];
-    return TensorView{net->slots[t[T_SLOT]], t[T_C], t[T_CP], t[T_H], t[T_W], t[T_DTYPE]};
+    const size_t per_image = (size_t)t[T_H] * t[T_W] * t[T_CP] * (t[T_DTYPE] == 1 ? 4 : 2);
+    return TensorView{(char *)net->slots[t[T_SLOT]] + per_image * first, t[T_C], t[T_CP], t[T_H], t[T_W], t[T_DTYPE]};
 }
 
-int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int batch, void *partial_ws) {
+// one op on images [first, first + batch) of the resident batch
+int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first, int batch, void *partial_ws) {
     const int32_t *op = &net->ops[(size_t)oi * FID_OP_WORDS];
     const char *blob = (const char *)net->blob;
-    const TensorView dst = view(net, op[W_DST]);
+    const TensorView dst = view(net, op[W_DST], first);
+    images += (size_t)first * net->in_h * net->in_w * 3;
     const float *bias = op[W_BOFF] >= 0 ? (const float *)(blob + op[W_BOFF]) : nullptr;
     const float *slope = op[W_SOFF] >= 0 ? (const float *)(blob + op[W_SOFF]) : nullptr;
     switch (op[W_TYPE]) {
@@ -175,7 +179,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int batch,
             break;
         }
         case OP_CONV: {
-            const TensorView src = view(net, op[W_SRC]);
+            const TensorView src = view(net, op[W_SRC], first);
             ConvArgs a{};
             a.in = src.ptr;
             a.w = blob + op[W_WOFF];
@@ -190,25 +194,29 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int batch,
             a.act = op[W_ACT]; a.flags = op[W_FLAGS]; a.nsig = op[W_NSIG];
             if (dst.dtype == 1) a.flags |= CF_OUT_F32;
             if (op[W_RES] >= 0) {
-                const TensorView r = view(net, op[W_RES]);
+                const TensorView r = view(net, op[W_RES], first);
                 a.res = r.ptr; a.res_H = r.H; a.res_W = r.W; a.res_Cp = r.Cp;
             }
             a.in_bytes = (unsigned)((size_t)batch * src.H * src.W * src.Cp * 2);
             a.w_bytes = (unsigned)op[W_WBYTES];
+            if (conv_direct_applicable(a)) {
+                FID_TRY(conv_direct_launch(ctx, a));
+                break;
+            }
             const ConvPlan plan = conv_plan(a, ctx->num_cus, partial_ws != nullptr);
             a.partial = (float *)partial_ws;
             FID_TRY(conv_launch(ctx, a, plan));
             break;
         }
         case OP_MAXPOOL: {
-            const TensorView src = view(net, op[W_SRC]);
+            const TensorView src = view(net, op[W_SRC], first);
             const long long total = (long long)batch * dst.H * dst.W * (dst.Cp / 8);
             hipLaunchKernelGGL(maxpool_nhwc, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, (const _Float16 *)src.ptr,
                                (_Float16 *)dst.ptr, src.H, src.W, dst.H, dst.W, dst.Cp, op[W_KH], op[W_STRIDE], op[W_PAD], total);
             break;
         }
         case OP_DWCONV: {
-            const TensorView src = view(net, op[W_SRC]);
+            const TensorView src = view(net, op[W_SRC], first);
             const long long total = (long long)batch * dst.H * dst.W * (dst.Cp / 8);
             hipLaunchKernelGGL(dwconv_nhwc, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, (const _Float16 *)src.ptr,
                                (const float *)(blob + op[W_WOFF]), bias, slope, (_Float16 *)dst.ptr, src.H, src.W, dst.H, dst.W,
@@ -242,7 +250,8 @@ int run_all(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float 
     FID_REQUIRE(batch > 0 && batch <= net->max_batch, "batch %d outside [1, %d]", batch, net->max_batch);
     std::lock_guard<std::mutex> lk(ctx->mu);
     void *partial_ws = nullptr;
-    const size_t need = partial_need(ctx, net, batch);
+    const int sbq = (!op_ms && net->sub_batch > 0) ? std::min(net->sub_batch, batch) : batch;
+    const size_t need = std::max(partial_need(ctx, net, sbq), partial_need(ctx, net, batch % sbq ? batch % sbq : sbq));
     if (need) FID_TRY(get_scratch(ctx, 1, need, &partial_ws));
     if (op_ms) {
         if (net->n_prof_events < net->n_ops + 1) {
@@ -252,9 +261,19 @@ int run_all(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float 
         }
         FID_HIP(hipEventRecord(net->prof_events[0], ctx->stream));
     }
-    for (int oi = 0; oi < net->n_ops; oi++) {
-        FID_TRY(run_op(ctx, net, oi, images, batch, need ? partial_ws : nullptr));
-        if (op_ms) FID_HIP(hipEventRecord(net->prof_events[oi + 1], ctx->stream));
+    if (op_ms) {   // per-op timing: whole batch per op (layer by layer)
+        for (int oi = 0; oi < net->n_ops; oi++) {
+            FID_TRY(run_op(ctx, net, oi, images, 0, batch, need ? partial_ws : nullptr));
+            FID_HIP(hipEventRecord(net->prof_events[oi + 1], ctx->stream));
+        }
+    } else {
+        // depth-first over sub-batches: every layer's input was written a moment ago by the previous
+        // layer of the SAME sub-batch and is still in L2 / Infinity Cache instead of coming back from HBM
+        const int sb = net->sub_batch > 0 ? net->sub_batch : batch;
+        for (int first = 0; first < batch; first += sb) {
+            const int nb = std::min(sb, batch - first);
+            for (int oi = 0; oi < net->n_ops; oi++) FID_TRY(run_op(ctx, net, oi, images, first, nb, need ? partial_ws : nullptr));
+        }
     }
     FID_HIP(hipGetLastError());
     if (op_ms) {
@@ -324,7 +343,14 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
     FID_HIP(hipMalloc(&net->blob, blob_bytes + 256));
     net->blob_bytes = blob_bytes;
     FID_HIP(hipMemcpy(net->blob, blob, blob_bytes, hipMemcpyHostToDevice));
+    if (const char *e = getenv("FID_SUB_BATCH")) net->sub_batch = atoi(e);
     *out = net;
+    return FID_OK;
+}
+
+int fid_net_set_sub_batch(fid_net *net, int sub_batch) {
+    FID_REQUIRE(net && sub_batch >= 0, "bad args");
+    net->sub_batch = sub_batch;
     return FID_OK;
 }
 
