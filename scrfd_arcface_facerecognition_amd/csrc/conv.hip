@@ -298,7 +298,38 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) co0[ni] = tn * BN + wn * TN + ni * 16 + fq * 4;
-    epilogue_tile<NI, MI>(ep, acc, px, co0);
+    if (a.flags & CF_OUT_F32) {
+        epilogue_tile<NI, MI>(ep, acc, px, co0);
+        return;
+    }
+    // fp16 output: transpose the wave's TM x TN tile through the (now idle) staging LDS so that every lane
+    // stores 16 contiguous bytes and a wave instruction covers whole pixel rows -- the 8-byte-per-lane
+    // accumulator layout touches 16 cache lines per store and made the stores the bottleneck
+    constexpr int OROWB = TN * 2, OCPP = TN / 8, PPI = 64 / OCPP;
+    constexpr int OMASK = (OCPP & (OCPP - 1)) == 0 ? OCPP - 1 : 0;
+    static_assert(4 * TM * OROWB <= 2 * (BM + BN) * BK * 2, "staging LDS too small for the output transpose");
+    ep_half4 hv[NI][MI];
+    epilogue_values<NI, MI>(ep, acc, px, co0, hv);
+    char *sS = smem + wave * (TM * OROWB);
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int p = mi * 16 + frow, c = ni * 2 + (fq >> 1);
+            *(ep_half4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4) + (fq & 1) * 8) = hv[ni][mi];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int m_base = tm * BM + wm * TM, co_base = tn * BN + wn * TN;
+#pragma unroll
+    for (int s2 = 0; s2 < (TM + PPI - 1) / PPI; s2++) {
+        const int p = s2 * PPI + lane / OCPP, c = lane % OCPP;
+        if (lane < PPI * OCPP && p < TM) {
+            const u32x4 v = *(const u32x4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4));
+            const int m = m_base + p;
+            if (m < a.M && co_base + c * 8 < a.Cout_p)
+                *(u32x4 *)((char *)a.out + ((size_t)m * a.Cout_p + co_base) * 2 + c * 16) = v;
+        }
+    }
 }
 
 // second pass of a split-K conv: sum the slabs in a fixed order (bit-reproducible), then the epilogue

@@ -28,6 +28,7 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB = 0x7FFFFFF0u;
 constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;  // 324 patch pixels
@@ -52,7 +53,7 @@ struct DirectArgs {
 };
 
 template <int CIN_P, int COUT_P>
-__global__ void __launch_bounds__(256, 1) conv3x3_direct(const DirectArgs a) {
+__global__ void __launch_bounds__(512, 2) conv3x3_direct(const DirectArgs a) {
     constexpr int ROWB = CIN_P * 2;            // bytes per pixel / per (tap, cout) weight row
     constexpr int CPP = ROWB / 16;             // 16-byte chunks per row
     constexpr int PXI = 64 / CPP;              // rows written by one wave-wide LDS-DMA instruction (1 KB)
@@ -62,18 +63,40 @@ __global__ void __launch_bounds__(256, 1) conv3x3_direct(const DirectArgs a) {
     constexpr int W_ROWS = 9 * COUT_P;
     constexpr int W_BYTES = W_ROWS * ROWB;
     constexpr int N_WINSTR = W_BYTES / 1024;
-    constexpr int MAX_PI = (N_PINSTR + 3) / 4; // patch instructions per wave
+    constexpr int MAX_PI = (N_PINSTR + 3) / 4 + 1; // patch instructions per wave of a group (upper bound)
     constexpr int NI = COUT_P / 16, MI = 4, KK = CIN_P / 32;
+    // output staging: each wave transposes its 64-pixel x COUT_P tile through LDS so that the global stores
+    // are 16 bytes per lane and cover whole pixel rows (1 KB contiguous per instruction) instead of 8-byte
+    // pieces scattered over 16 cache lines -- the stores were the bottleneck of the HBM-bound layers.
+    constexpr int OROWB = COUT_P * 2;           // bytes per output pixel
+    constexpr int OCPP = OROWB / 16;            // 16-byte chunks per output pixel
+    constexpr int SCR_BYTES = 64 * OROWB;       // per wave
+    constexpr bool SCR_DEDICATED = W_BYTES + 2 * PATCH_BYTES + 8 * SCR_BYTES <= 160 * 1024;
+    static_assert(SCR_DEDICATED || 4 * SCR_BYTES <= (N_PINSTR - 4) * 1024, "patch buffer too small to double as staging");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sW = smem;                            // [9][COUT_P][CIN_P] fp16, tap-major
-    char *sP = smem + W_BYTES;                  // [2][PATCH_ROWS][CIN_P]
+    char *sW = smem;                            // [9][COUT_P][CIN_P] fp16, tap-major, shared by both groups
 
+    // 8 waves = two groups of 4 (one wave of each group per SIMD).  The groups work on different tiles
+    // and run half a period apart: while one group's waves feed the matrix cores from LDS, the other
+    // group stores its finished tile and fetches its next patch (ping-pong; one workgroup barrier per
+    // half period keeps them interleaved).
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wg = wave & 3;
+    char *sP = smem + W_BYTES + grp * PATCH_BYTES;   // this group's patch [PATCH_ROWS][CIN_P]
+    // staging area of this wave: a dedicated region when LDS allows, else the first 4*SCR_BYTES of the group's
+    // (then dead) patch buffer; in that case each wave only DMAs into the 1 KB blocks it owns (its own staging
+    // blocks + a share of the tail), so no wave's next patch can land on another wave's unread staging data
+    char *sS = SCR_DEDICATED ? smem + W_BYTES + 2 * PATCH_BYTES + (grp * 4 + wg) * SCR_BYTES : sP + wg * SCR_BYTES;
+    constexpr int SCR_BLKS = SCR_BYTES / 1024;       // 1 KB DMA blocks per wave staging area
+    auto dma_block = [&](int k) {                    // k-th patch block this wave fills
+        if (SCR_DEDICATED) return wg + 4 * k;
+        return k < SCR_BLKS ? wg * SCR_BLKS + k : 4 * SCR_BLKS + wg + 4 * (k - SCR_BLKS);
+    };
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
 
     // ---- filter bank -> LDS (once per workgroup) ----
-    for (int j = wave; j < N_WINSTR; j += 4) {
+    for (int j = wave; j < N_WINSTR; j += 8) {
         const int p = j * 64 + lane;            // 16-byte position in the LDS image
         const int row = p / CPP, slot = p % CPP;
         const int t = row / COUT_P, co = row - t * COUT_P;
@@ -86,7 +109,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_direct(const DirectArgs a) {
     int p_py[MAX_PI], p_px[MAX_PI], p_ch[MAX_PI];
 #pragma unroll
     for (int k = 0; k < MAX_PI; k++) {
-        const int j = wave + 4 * k;
+        const int j = dma_block(k);
         const int lin = j * PXI + lane / CPP;
         p_py[k] = lin / PW;
         p_px[k] = lin - p_py[k] * PW;
@@ -94,67 +117,68 @@ __global__ void __launch_bounds__(256, 1) conv3x3_direct(const DirectArgs a) {
         if (j >= N_PINSTR || lin >= NPIX) p_py[k] = -100000;  // never inside an image
     }
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    auto fetch_patch = [&](int tile, int buf) {
+    auto fetch_patch = [&](int tile) {
         const int n = tile / tiles_per_img;
         const int r = tile - n * tiles_per_img;
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
         const int y0 = ty * TH - 1, x0 = tx * TW - 1;
 #pragma unroll
         for (int k = 0; k < MAX_PI; k++) {
-            const int j = wave + 4 * k;
+            const int j = dma_block(k);
             if (j < N_PINSTR) {
                 const int iy = y0 + p_py[k], ix = x0 + p_px[k];
                 const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * CIN_P + p_ch[k]) * 2) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(sP + buf * PATCH_BYTES + j * 1024),
-                                                         16, vo, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(sP + j * 1024), 16, vo, 0, 0, 0);
             }
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < a.n_tiles) fetch_patch(tile, 0);
+    // pair q of this workgroup = tiles (2q, 2q+1): group 0 takes the even one, group 1 the odd one
+    const int n_pairs = (a.n_tiles + 1) >> 1;
+    const int my_pairs = blockIdx.x < n_pairs ? (n_pairs - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    auto tile_of = [&](int i) { return (blockIdx.x + i * gridDim.x) * 2 + grp; };
+
+    if (my_pairs > 0 && tile_of(0) < a.n_tiles) fetch_patch(tile_of(0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     EpiArgs ep{a.bias, a.slope, a.res, a.out, COUT_P, a.H, a.W, a.act, a.flags, a.nsig, a.H, a.W, a.res_Cp};
     const int frow = lane & 15, fq = lane >> 4;
-    const int lin0 = (wave * MI) * PW + frow;   // patch pixel of (tile row wave*4, tile col frow), tap (0,0)
-    int it = 0;
-    for (; tile < a.n_tiles; tile += gridDim.x, it++) {
-        const int cur = it & 1;
-        const int next = tile + gridDim.x;
-        if (next < a.n_tiles) fetch_patch(next, cur ^ 1);
-        const char *P = sP + cur * PATCH_BYTES;
+    const int lin0 = (wg * MI) * PW + frow;   // patch pixel of (tile row wg*4, tile col frow), tap (0,0)
+    if (grp == 1) __syncthreads();            // half-period phase shift of group 1
+    for (int i = 0; i < my_pairs; i++) {
+        const int tile = tile_of(i);
+        const bool have = tile < a.n_tiles;
+        const int next = tile_of(i + 1);
+        const bool have_next = (i + 1 < my_pairs) && next < a.n_tiles;
 
-        // epilogue operands (bias rows, residual values) are requested now and arrive during the K loop
         EpiPix px[MI];
         int co0[NI];
         {
-            const int n = tile / tiles_per_img;
-            const int r = tile - n * tiles_per_img;
+            const int tl = have ? tile : 0;
+            const int n = tl / tiles_per_img;
+            const int r = tl - n * tiles_per_img;
             const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
             const int ox = tx * TW + frow;
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) {
-                const int oy = ty * TH + wave * MI + mi;
-                px[mi].valid = oy < a.H && ox < a.W;
+                const int oy = ty * TH + wg * MI + mi;
+                px[mi].valid = have && oy < a.H && ox < a.W;
                 px[mi].n = n; px[mi].oy = oy; px[mi].ox = ox;
                 px[mi].m = px[mi].valid ? ((long long)n * a.H + oy) * a.W + ox : 0;
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) co0[ni] = ni * 16 + fq * 4;
         }
-        EpiRegs<NI, MI> R;
-        epilogue_prefetch<NI, MI>(ep, px, co0, R);
-
         f32x4 acc[NI][MI];
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        if (!(a.flags & (1 << 28)))
+        // ---- compute half-period: 9 taps x Cin_p/32 MFMA steps out of LDS, no barrier inside ----
+        if (have && !(a.flags & (1 << 28)))
 #pragma unroll
         for (int t = 0; t < 9; t++) {
             const int dy = t / 3, dx = t % 3;
@@ -169,7 +193,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_direct(const DirectArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++) {
                     const int lin = lin0 + (mi + dy) * PW + dx;
-                    pf[mi] = *(const half8 *)(P + lin * ROWB + (((kk * 4 + fq) ^ swz<ROWB>(lin)) << 4));
+                    pf[mi] = *(const half8 *)(sP + lin * ROWB + (((kk * 4 + fq) ^ swz<ROWB>(lin)) << 4));
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ni++)
@@ -178,29 +202,64 @@ __global__ void __launch_bounds__(256, 1) conv3x3_direct(const DirectArgs a) {
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[mi], acc[ni][mi], 0, 0, 0);
             }
         }
+        __syncthreads();   // my group is done reading its patch; the other group starts computing
 
-        // the next patch (requested before the K loop) has long landed: this wait is free, and it is placed
-        // BEFORE the output stores so that those stay in flight across the barrier
+        // ---- memory half-period: store my finished tile, fetch my next patch (latency hides behind the other group) ----
+        if (SCR_DEDICATED && have_next) fetch_patch(next);
+        if (have && !(a.flags & (1 << 29))) {
+            if (a.flags & CF_OUT_F32) {
+                epilogue_tile<NI, MI>(ep, acc, px, co0);
+            } else {
+                ep_half4 hv[NI][MI];
+                epilogue_values<NI, MI>(ep, acc, px, co0, hv);
+                // wave-local transpose: lane (pixel frow of row mi, cout group fq) -> [pixel][chunk ^ (pixel & (OCPP-1))]
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) {
+                        const int p = mi * 16 + frow, c = ni * 2 + (fq >> 1);
+                        *(ep_half4 *)(sS + p * OROWB + ((c ^ (p & (OCPP - 1))) << 4) + (fq & 1) * 8) = hv[ni][mi];
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int n = tile / tiles_per_img;
+                const int r = tile - n * tiles_per_img;
+                const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+                constexpr int PPI = 64 / OCPP;         // pixels per store instruction
+#pragma unroll
+                for (int s2 = 0; s2 < 64 / PPI; s2++) {
+                    const int p = s2 * PPI + lane / OCPP, c = lane % OCPP;
+                    const u32x4 v = *(const u32x4 *)(sS + p * OROWB + ((c ^ (p & (OCPP - 1))) << 4));
+                    const int oy = ty * TH + wg * MI + (p >> 4), ox = tx * TW + (p & 15);
+                    if (oy < a.H && ox < a.W)
+                        *(u32x4 *)((char *)a.out + ((((size_t)n * a.H + oy) * a.W + ox) * OROWB) + c * 16) = v;
+                }
+            }
+        }
+        if (!SCR_DEDICATED) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads returned before the DMA may overwrite them
+            if (have_next) fetch_patch(next);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(a.flags & (1 << 29))) epilogue_finish<NI, MI>(ep, acc, px, co0, R);
-        else if (acc[0][0][0] == 12345.678f) epilogue_finish<NI, MI>(ep, acc, px, co0, R);
-        __syncthreads();
+        __syncthreads();   // patches landed; roles swap
     }
+    if (grp == 0) __syncthreads();
 }
 
 template <int CIN_P, int COUT_P>
 int launch_direct(fid_ctx *ctx, const DirectArgs &a) {
     constexpr int ROWB = CIN_P * 2, PXI = 64 / (ROWB / 16);
     constexpr int PATCH_BYTES = ((NPIX + PXI - 1) / PXI) * PXI * ROWB;
-    constexpr size_t lds = (size_t)9 * COUT_P * ROWB + 2 * PATCH_BYTES;
+    constexpr size_t base = (size_t)9 * COUT_P * ROWB + 2 * PATCH_BYTES;
+    constexpr size_t scr = (size_t)8 * 64 * COUT_P * 2;
+    constexpr size_t lds = base + scr <= 160 * 1024 ? base + scr : base;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
         FID_HIP(hipFuncSetAttribute((const void *)conv3x3_direct<CIN_P, COUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int grid = std::min(a.n_tiles, ctx->num_cus);
-    hipLaunchKernelGGL((conv3x3_direct<CIN_P, COUT_P>), dim3(grid), dim3(256), lds, ctx->stream, a);
+    const int grid = std::min((a.n_tiles + 1) / 2, ctx->num_cus);
+    hipLaunchKernelGGL((conv3x3_direct<CIN_P, COUT_P>), dim3(grid), dim3(512), lds, ctx->stream, a);
     return FID_OK;
 }
 

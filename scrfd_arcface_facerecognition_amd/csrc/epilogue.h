@@ -28,10 +28,10 @@ struct EpiPix {   // one output pixel column of the tile
 };
 
 template <int NI, int MI>
-struct EpiRegs {          // everything the epilogue reads from memory, for one tile
-    ep_half4 rr[NI][MI];
-    ep_f32x4 bb[NI][MI];
-    ep_f32x4 sl[NI];
+struct EpiRegs {          // what the epilogue reads from memory ahead of time, for one tile
+    ep_half4 rr[NI][MI];  // residual values
+    ep_f32x4 bb[NI];      // bias row (border-class bias rows are fetched late: they differ per pixel)
+    ep_f32x4 sl[NI];      // PReLU slopes
 };
 
 template <int NI, int MI>
@@ -50,20 +50,10 @@ __device__ __forceinline__ void epilogue_prefetch(const EpiArgs &e, const EpiPix
     // ---- phase 1: every load of the tile ----
     const bool has_bias = e.bias != nullptr;
 #pragma unroll
-    for (int mi = 0; mi < MI; mi++) {
+    for (int ni = 0; ni < NI; ni++) bb[ni] = ep_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_bias && !border) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++) bb[ni][mi] = ep_f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (has_bias)
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++) {
-        int cls = 0;
-        if (border) cls = (px[mi].oy == 0 ? 0 : (px[mi].oy == e.Ho - 1 ? 2 : 1)) * 3 + (px[mi].ox == 0 ? 0 : (px[mi].ox == e.Wo - 1 ? 2 : 1));
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++) {
-            const int c = co0[ni] < e.Cout_p ? co0[ni] : 0;
-            bb[ni][mi] = *(const ep_f32x4 *)(e.bias + (size_t)cls * e.Cout_p + c);
-        }
+        for (int ni = 0; ni < NI; ni++) bb[ni] = *(const ep_f32x4 *)(e.bias + (co0[ni] < e.Cout_p ? co0[ni] : 0));
     }
     if (has_res) {
 #pragma unroll
@@ -94,11 +84,18 @@ __device__ __forceinline__ void epilogue_finish(const EpiArgs &e, ep_f32x4 (&acc
     const auto &bb = R.bb;
     const auto &sl = R.sl;
     // ---- phase 2: arithmetic + stores ----
+    const bool border = (e.flags & CF_BORDER) != 0;
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
+        ep_f32x4 bm[NI];
+        if (border) {   // exact fold of a BatchNorm in front of a zero-padded conv: the bias row depends on the pixel
+            const int cls = (px[mi].oy == 0 ? 0 : (px[mi].oy == e.Ho - 1 ? 2 : 1)) * 3 + (px[mi].ox == 0 ? 0 : (px[mi].ox == e.Wo - 1 ? 2 : 1));
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) bm[ni] = *(const ep_f32x4 *)(e.bias + (size_t)cls * e.Cout_p + (co0[ni] < e.Cout_p ? co0[ni] : 0));
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
-            ep_f32x4 v = acc[ni][mi] + bb[ni][mi];
+            ep_f32x4 v = acc[ni][mi] + (border ? bm[ni] : bb[ni]);
             if (has_res) {
                 v[0] += (float)rr[ni][mi][0]; v[1] += (float)rr[ni][mi][1];
                 v[2] += (float)rr[ni][mi][2]; v[3] += (float)rr[ni][mi][3];
@@ -124,6 +121,43 @@ __device__ __forceinline__ void epilogue_finish(const EpiArgs &e, ep_f32x4 (&acc
                     *(ep_half4 *)((_Float16 *)e.out + (size_t)px[mi].m * e.Cout_p + co0[ni]) = h;
                 }
             }
+        }
+    }
+}
+
+// bias + residual + activation in the accumulator layout, result as fp16 (no store): for kernels that
+// transpose the tile through LDS and write whole 128-byte lines
+template <int NI, int MI>
+__device__ __forceinline__ void epilogue_values(const EpiArgs &e, ep_f32x4 (&acc)[NI][MI], const EpiPix (&px)[MI], const int (&co0)[NI],
+                                                ep_half4 (&h)[NI][MI]) {
+    EpiRegs<NI, MI> R;
+    epilogue_prefetch<NI, MI>(e, px, co0, R);
+    const bool has_res = e.res != nullptr;
+    const bool border = (e.flags & CF_BORDER) != 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+        ep_f32x4 bm[NI];
+        if (border) {
+            const int cls = (px[mi].oy == 0 ? 0 : (px[mi].oy == e.Ho - 1 ? 2 : 1)) * 3 + (px[mi].ox == 0 ? 0 : (px[mi].ox == e.Wo - 1 ? 2 : 1));
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) bm[ni] = *(const ep_f32x4 *)(e.bias + (size_t)cls * e.Cout_p + (co0[ni] < e.Cout_p ? co0[ni] : 0));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            ep_f32x4 v = acc[ni][mi] + (border ? bm[ni] : R.bb[ni]);
+            if (has_res) {
+                v[0] += (float)R.rr[ni][mi][0]; v[1] += (float)R.rr[ni][mi][1];
+                v[2] += (float)R.rr[ni][mi][2]; v[3] += (float)R.rr[ni][mi][3];
+            }
+            if (e.act == ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.f);
+            } else if (e.act == ACT_PRELU) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = v[i] > 0.f ? v[i] : v[i] * R.sl[ni][i];
+            }
+            h[ni][mi][0] = (_Float16)v[0]; h[ni][mi][1] = (_Float16)v[1];
+            h[ni][mi][2] = (_Float16)v[2]; h[ni][mi][3] = (_Float16)v[3];
         }
     }
 }
