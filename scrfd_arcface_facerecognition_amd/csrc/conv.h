@@ -34,9 +34,15 @@ struct ConvArgs {
 // must hold ksplit*M*Cout_p floats when the plan splits K (query with conv_plan first).
 struct ConvPlan {
     int bm, bn, bk, ksplit;
+    int gen;   // 1 = register-staged double buffer, 2 = LDS-DMA ring (BK = 64)
+    int ns;    // ring slots (gen 2)
     size_t partial_bytes;
 };
 ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split);
+// every kernel/tile/split combination worth timing for this conv (gen 0 = conv_direct); used by the
+// executor's per-layer autotuner (net.hip) -- "measure, don't guess"
+#include <vector>
+std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split);
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan);
 
 // conv_direct.hip: 3x3/s1 conv with LDS-resident weights + haloed patches (<= 64 channels in and out)

@@ -103,6 +103,105 @@ __device__ __forceinline__ void epilogue4(const ConvArgs &a, int m, int co0, f32
     }
 }
 
+// ---- tile epilogue shared by both kernel generations: lane holds couts co0..co0+3 (rows of D) of pixel m
+// (column of D); `smem` is the (idle) staging LDS, at least LDS_BYTES large ----
+template <int BM, int BN, int WM, int WN, int LDS_BYTES>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs &a, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int tm, int tn, int split,
+                                              char *smem) {
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fq = lane >> 4;
+    // ---- epilogue: lane holds couts co0..co0+3 (rows of D) of pixel `m` (column of D) ----
+    if (a.flags & CF_ARGMAX) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            const int m = tm * BM + wm * TM + mi * 16 + frow;
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int co0 = tn * BN + wn * TN + ni * 16 + fq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (co0 + j < a.Cout_p) {
+                        const unsigned long long key = ((unsigned long long)sortable(acc[ni][mi][j]) << 32) | (unsigned)(~(unsigned)(co0 + j));
+                        best = key > best ? key : best;
+                    }
+                }
+            }
+            // the 4 lanes l, l^16, l^32, l^48 hold the same pixel
+            unsigned long long o = __shfl_xor(best, 16);
+            best = o > best ? o : best;
+            o = __shfl_xor(best, 32);
+            best = o > best ? o : best;
+            if (fq == 0 && m < a.M) atomicMax(a.amax + m, best);
+        }
+        return;
+    }
+    if (a.ksplit > 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            const int m = tm * BM + wm * TM + mi * 16 + frow;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int co0 = tn * BN + wn * TN + ni * 16 + fq * 4;
+                if (co0 < a.Cout_p) *(f32x4 *)(a.partial + ((size_t)split * a.M + m) * a.Cout_p + co0) = acc[ni][mi];
+            }
+        }
+        return;
+    }
+    const bool need_pix = (a.flags & (CF_BORDER | CF_RES_UP2)) != 0;
+    EpiArgs ep{a.bias, a.slope, a.res, a.out, a.Cout_p, a.Ho, a.Wo, a.act, a.flags, a.nsig, a.res_H, a.res_W, a.res_Cp};
+    EpiPix px[MI];
+    int co0[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+        const int m = tm * BM + wm * TM + mi * 16 + frow;
+        px[mi].valid = m < a.M;
+        px[mi].m = px[mi].valid ? m : 0;
+        px[mi].n = px[mi].oy = px[mi].ox = 0;
+        if (need_pix && px[mi].valid) {
+            const Pix p = decompose(a, m);
+            px[mi].n = p.n; px[mi].oy = p.oy; px[mi].ox = p.ox;
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) co0[ni] = tn * BN + wn * TN + ni * 16 + fq * 4;
+    if (a.flags & CF_OUT_F32) {
+        epilogue_tile<NI, MI>(ep, acc, px, co0);
+        return;
+    }
+    // fp16 output: transpose the wave's TM x TN tile through the (now idle) staging LDS so that every lane
+    // stores 16 contiguous bytes and a wave instruction covers whole pixel rows -- the 8-byte-per-lane
+    // accumulator layout touches 16 cache lines per store and made the stores the bottleneck
+    constexpr int OROWB = TN * 2, OCPP = TN / 8, PPI = 64 / OCPP;
+    constexpr int OMASK = (OCPP & (OCPP - 1)) == 0 ? OCPP - 1 : 0;
+    static_assert(4 * TM * OROWB <= LDS_BYTES, "staging LDS too small for the output transpose");
+    ep_half4 hv[NI][MI];
+    epilogue_values<NI, MI>(ep, acc, px, co0, hv);
+    char *sS = smem + wave * (TM * OROWB);
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int p = mi * 16 + frow, c = ni * 2 + (fq >> 1);
+            *(ep_half4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4) + (fq & 1) * 8) = hv[ni][mi];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int m_base = tm * BM + wm * TM, co_base = tn * BN + wn * TN;
+#pragma unroll
+    for (int s2 = 0; s2 < (TM + PPI - 1) / PPI; s2++) {
+        const int p = s2 * PPI + lane / OCPP, c = lane % OCPP;
+        if (lane < PPI * OCPP && p < TM) {
+            const u32x4 v = *(const u32x4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4));
+            const int m = m_base + p;
+            if (m < a.M && co_base + c * 8 < a.Cout_p)
+                *(u32x4 *)((char *)a.out + ((size_t)m * a.Cout_p + co_base) * 2 + c * 16) = v;
+        }
+    }
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -242,94 +341,162 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds couts co0..co0+3 (rows of D) of pixel `m` (column of D) ----
-    if (a.flags & CF_ARGMAX) {
+    tile_epilogue<BM, BN, WM, WN, 2 * (BM + BN) * BK * 2>(a, acc, tm, tn, split, smem);
+}
+
+// ================================================================================================
+// Generation 2: LDS-DMA ring.  Same GEMM view and fragment layout as conv_mfma_kernel, but
+//   * tiles go global -> LDS directly (buffer_load ... lds, 1 KB per wave instruction: no VGPR staging, no
+//     ds_write), swizzle applied to each lane's SOURCE address, destination lane-linear;
+//   * NS ring slots, NS-1 K-steps in flight behind a COUNTED s_waitcnt vmcnt (never 0 in the loop) and one raw
+//     s_barrier per K-step.  With one K-step of prefetch (generation 1) a K-step costs one L2 round trip
+//     (~1.1 us measured: 14 % MFMA utilisation on the 14x14 layers); with 3 in flight the trip is amortised;
+//   * all per-K-step addressing is wave-uniform scalar work (tap, channel chunk) plus one select per row.
+// ================================================================================================
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int BK, int NS, int WM, int WN>
+__global__ void __launch_bounds__(256, (NS * (BM + (BN + 256 / (BK / 8) - 1) / (256 / (BK / 8)) * (256 / (BK / 8))) * BK * 2 <= 80 * 1024) ? 2 : 1)
+    conv_mfma_dma_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int ROWB = BK * 2, CPR = BK / 8;       // bytes / 16-byte chunks per staged row
+    constexpr int RPW = 64 / CPR, RPP = 4 * RPW;     // rows per 1 KB wave instruction / per pass of the 4 waves
+    constexpr int BN_ALLOC = (BN + RPP - 1) / RPP * RPP;
+    constexpr int A_LD = BM / RPP, B_LD = BN_ALLOC / RPP, L = A_LD + B_LD;   // DMA instructions per wave per stage
+    constexpr int STAGE = (BM + BN_ALLOC) * ROWB;
+    static_assert(WM * WN == 4 && BM % RPP == 0 && NS >= 2 && NS <= 4 && NS * STAGE <= 160 * 1024, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    const int Lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tn = Lid % a.tiles_n, tm = Lid / a.tiles_n;
+    const int split = blockIdx.y;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = wave * RPW + lane / CPR;                     // row inside a pass
+    const int my_chunk = (lane % CPR) ^ swz<BK>(lrow);            // K chunk this lane fetches: LDS slot ^ swizzle(row)
+
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+
+    int a_off[A_LD];
+    unsigned a_mask[A_LD];
 #pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-            const int m = tm * BM + wm * TM + mi * 16 + frow;
-            unsigned long long best = 0ull;
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-                const int co0 = tn * BN + wn * TN + ni * 16 + fq * 4;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (co0 + j < a.Cout_p) {
-                        const unsigned long long key = ((unsigned long long)sortable(acc[ni][mi][j]) << 32) | (unsigned)(~(unsigned)(co0 + j));
-                        best = key > best ? key : best;
-                    }
-                }
-            }
-            // the 4 lanes l, l^16, l^32, l^48 hold the same pixel
-            unsigned long long o = __shfl_xor(best, 16);
-            best = o > best ? o : best;
-            o = __shfl_xor(best, 32);
-            best = o > best ? o : best;
-            if (fq == 0 && m < a.M) atomicMax(a.amax + m, best);
-        }
-        return;
-    }
-    if (a.ksplit > 1) {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-            const int m = tm * BM + wm * TM + mi * 16 + frow;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-                const int co0 = tn * BN + wn * TN + ni * 16 + fq * 4;
-                if (co0 < a.Cout_p) *(f32x4 *)(a.partial + ((size_t)split * a.M + m) * a.Cout_p + co0) = acc[ni][mi];
-            }
-        }
-        return;
-    }
-    const bool need_pix = (a.flags & (CF_BORDER | CF_RES_UP2)) != 0;
-    EpiArgs ep{a.bias, a.slope, a.res, a.out, a.Cout_p, a.Ho, a.Wo, a.act, a.flags, a.nsig, a.res_H, a.res_W, a.res_Cp};
-    EpiPix px[MI];
-    int co0[NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++) {
-        const int m = tm * BM + wm * TM + mi * 16 + frow;
-        px[mi].valid = m < a.M;
-        px[mi].m = px[mi].valid ? m : 0;
-        px[mi].n = px[mi].oy = px[mi].ox = 0;
-        if (need_pix && px[mi].valid) {
+    for (int i = 0; i < A_LD; i++) {
+        const int m = tm * BM + i * RPP + lrow;
+        a_off[i] = 0;
+        a_mask[i] = 0;
+        if (m < a.M) {
             const Pix p = decompose(a, m);
-            px[mi].n = p.n; px[mi].oy = p.oy; px[mi].ox = p.ox;
+            const int iy0 = p.oy * a.stride - a.pad, ix0 = p.ox * a.stride - a.pad;
+            a_off[i] = ((p.n * a.H + iy0) * a.W + ix0) * a.Cin_p + my_chunk * 8;
+            unsigned mask = 0;
+            for (int t = 0; t < a.T; t++) {
+                const int dy = t / a.kw, dx = t - dy * a.kw;
+                if ((unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W) mask |= 1u << t;
+            }
+            a_mask[i] = mask;
         }
     }
+    int b_off[B_LD];
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++) co0[ni] = tn * BN + wn * TN + ni * 16 + fq * 4;
-    if (a.flags & CF_OUT_F32) {
-        epilogue_tile<NI, MI>(ep, acc, px, co0);
-        return;
+    for (int i = 0; i < B_LD; i++) {
+        const int row = i * RPP + lrow, co = tn * BN + row;
+        b_off[i] = (row < BN && co < a.w_rows) ? co * a.T * a.Cin_p + my_chunk * 8 : -1;
     }
-    // fp16 output: transpose the wave's TM x TN tile through the (now idle) staging LDS so that every lane
-    // stores 16 contiguous bytes and a wave instruction covers whole pixel rows -- the 8-byte-per-lane
-    // accumulator layout touches 16 cache lines per store and made the stores the bottleneck
-    constexpr int OROWB = TN * 2, OCPP = TN / 8, PPI = 64 / OCPP;
-    constexpr int OMASK = (OCPP & (OCPP - 1)) == 0 ? OCPP - 1 : 0;
-    static_assert(4 * TM * OROWB <= 2 * (BM + BN) * BK * 2, "staging LDS too small for the output transpose");
-    ep_half4 hv[NI][MI];
-    epilogue_values<NI, MI>(ep, acc, px, co0, hv);
-    char *sS = smem + wave * (TM * OROWB);
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++) {
-            const int p = mi * 16 + frow, c = ni * 2 + (fq >> 1);
-            *(ep_half4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4) + (fq & 1) * 8) = hv[ni][mi];
+
+    const int ks_begin = split * a.ksteps_per_split;
+    const int ks_end = min(a.ksteps, ks_begin + a.ksteps_per_split);
+    const int nk = ks_end - ks_begin;
+    // wave-uniform position of the next stage to issue: tap (dy, dx) and channel chunk
+    int tap = ks_begin / a.nchunk, ch = ks_begin - tap * a.nchunk;
+    int tdy = tap / a.kw, tdx = tap - tdy * a.kw;
+
+    // one DMA instruction (1 KB) of the stage being issued: j < A_LD -> activation rows, else weight rows
+    int adelta = 0, bdelta = 0;
+    auto stage_begin = [&]() {
+        adelta = (tdy * a.W + tdx) * a.Cin_p + ch * BK;
+        bdelta = tap * a.Cin_p + ch * BK;
+    };
+    auto stage_piece = [&](int slot, int j) {
+        char *dst = smem + slot * STAGE + wave * 1024;
+        if (j < A_LD) {
+            const unsigned vo = ((a_mask[j] >> tap) & 1u) ? (unsigned)(a_off[j] + adelta) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 4096), 16, vo, 0, 0, 0);
+        } else {
+            const int i = j - A_LD;
+            const unsigned vo = b_off[i] >= 0 ? (unsigned)(b_off[i] + bdelta) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(dst + BM * ROWB + i * 4096), 16, vo, 0, 0, 0);
         }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int m_base = tm * BM + wm * TM, co_base = tn * BN + wn * TN;
-#pragma unroll
-    for (int s2 = 0; s2 < (TM + PPI - 1) / PPI; s2++) {
-        const int p = s2 * PPI + lane / OCPP, c = lane % OCPP;
-        if (lane < PPI * OCPP && p < TM) {
-            const u32x4 v = *(const u32x4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4));
-            const int m = m_base + p;
-            if (m < a.M && co_base + c * 8 < a.Cout_p)
-                *(u32x4 *)((char *)a.out + ((size_t)m * a.Cout_p + co_base) * 2 + c * 16) = v;
+    };
+    auto stage_end = [&]() {
+        if (++ch == a.nchunk) {
+            ch = 0;
+            ++tap;
+            if (++tdx == a.kw) { tdx = 0; ++tdy; }
         }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; s++)
+        if (s < nk) {
+            stage_begin();
+#pragma unroll
+            for (int j = 0; j < L; j++) stage_piece(s, j);
+            stage_end();
+        }
+
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr int KK = BK / 32;
+    for (int k = 0; k < nk; k++) {
+        // stage k must have landed: allow only the younger stages (at most NS-2 of them) to be outstanding
+        const int younger = min(NS - 2, nk - 1 - k);
+        if (younger >= 2) wait_vmcnt<(NS >= 4 ? 2 : 0) * L>();
+        else if (younger == 1) wait_vmcnt<(NS >= 3 ? 1 : 0) * L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();       // everyone's DMAs of stage k landed; everyone is done reading slot (k-1)%NS
+        const bool more = k + NS - 1 < nk;
+        const int nslot = (k + NS - 1) % NS;
+        if (more) {      // (spreading these between the MFMA groups was measured: 3-4 % slower)
+            stage_begin();
+#pragma unroll
+            for (int j = 0; j < L; j++) stage_piece(nslot, j);
+        }
+        const char *cA = smem + (k % NS) * STAGE, *cB = cA + BM * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            half8 wf[NI], pf[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int row = wm * TM + mi * 16 + frow;
+                pf[mi] = *(const half8 *)(cA + row * ROWB + (((kk * 4 + fq) ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int row = wn * TN + ni * 16 + frow;
+                wf[ni] = *(const half8 *)(cB + row * ROWB + (((kk * 4 + fq) ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (more) stage_end();
     }
+    __syncthreads();   // all LDS reads done before the epilogue reuses the ring as staging
+    tile_epilogue<BM, BN, WM, WN, NS * STAGE>(a, acc, tm, tn, split, smem);
 }
 
 // second pass of a split-K conv: sum the slabs in a fixed order (bit-reproducible), then the epilogue
@@ -358,52 +525,127 @@ int launch_cfg(fid_ctx *ctx, const ConvArgs &a) {
     return FID_OK;
 }
 
+template <int BM, int BN, int BK, int NS, int WM, int WN>
+int launch_dma(fid_ctx *ctx, const ConvArgs &a) {
+    constexpr int RPP = 4 * (64 / (BK / 8));
+    constexpr size_t lds = (size_t)NS * (BM + (BN + RPP - 1) / RPP * RPP) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FID_HIP(hipFuncSetAttribute((const void *)conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, a.ksplit);
+    hipLaunchKernelGGL((conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN>), grid, dim3(256), lds, ctx->stream, a);
+    return FID_OK;
+}
+
 }  // namespace
 
+static bool dma_have(int bm, int bn, int bk) {
+    if (bk == 64) return (bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64);
+    return bm == 128 && (bn == 128 || bn == 96 || bn == 64 || bn == 32);
+}
+
 ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
-    ConvPlan p;
-    p.bk = (a.Cin_p % 64 == 0) ? 64 : 32;
-    const int ksteps = a.kh * a.kw * (a.Cin_p / p.bk);
-    if (p.bk == 64) {
-        p.bn = a.Cout_p >= 128 ? 128 : 64;
+    ConvPlan p{};
+    static const bool use_v1 = getenv("FID_CONV_V1") != nullptr;
+    auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
+    if (!use_v1) {
+        // ---- generation 2: LDS-DMA ring, BK = 64 over the flattened (tap, channel) axis ----
+        p.gen = 2; p.bk = (a.Cin_p % 64 == 0) ? 64 : 32; p.ns = 4;
         p.bm = 128;
-        auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
-        if (tiles(p.bm, p.bn) < 2LL * num_cus && p.bn == 128) p.bn = 64;
-        if (tiles(p.bm, p.bn) < 2LL * num_cus) p.bm = 64, p.bn = 64;
+        if (a.Cout_p % 128 == 0) p.bn = 128;
+        else if (a.Cout_p % 96 == 0) p.bn = 96;
+        else if (a.Cout_p > 64) p.bn = 128;
+        else p.bn = a.Cout_p > 32 ? 64 : 32;
+        // too few tiles to occupy the chip: smaller tiles (twice as many blocks, two resident per CU)
+        if (tiles(p.bm, p.bn) < (long long)num_cus && p.bn == 128) p.bn = 64;
+        if (tiles(p.bm, p.bn) < (long long)num_cus && p.bn == 64 && p.bk == 64) p.bm = 64;
+        if (p.bk == 64 && p.bn != 128 && p.bn != 64) p.bn = a.Cout_p > 64 ? 128 : 64;
     } else {
-        p.bm = 128;
-        p.bn = a.Cout_p >= 128 ? 128 : (a.Cout_p > 64 ? 96 : (a.Cout_p > 32 ? 64 : 32));
-        if (a.Cout_p % 96 == 0 && a.Cout_p % 128 != 0) p.bn = 96;      // 96 / 288-wide layers: no half-empty column tile
-        auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
-        if (tiles(p.bm, p.bn) < 2LL * num_cus && p.bn == 128) p.bn = 64;
+        p.gen = 1;
+        p.bk = (a.Cin_p % 64 == 0) ? 64 : 32;
+        if (p.bk == 64) {
+            p.bn = a.Cout_p >= 128 ? 128 : 64;
+            p.bm = 128;
+            if (tiles(p.bm, p.bn) < 2LL * num_cus && p.bn == 128) p.bn = 64;
+            if (tiles(p.bm, p.bn) < 2LL * num_cus) p.bm = 64, p.bn = 64;
+        } else {
+            p.bm = 128;
+            p.bn = a.Cout_p >= 128 ? 128 : (a.Cout_p > 64 ? 96 : (a.Cout_p > 32 ? 64 : 32));
+            if (a.Cout_p % 96 == 0 && a.Cout_p % 128 != 0) p.bn = 96;
+            if (tiles(p.bm, p.bn) < 2LL * num_cus && p.bn == 128) p.bn = 64;
+        }
     }
-    const long long t = (long long)cdiv(a.M, p.bm) * cdiv(a.Cout_p, p.bn);
+    const int ksteps = cdiv(a.kh * a.kw * a.Cin_p, p.bk);
+    const long long t = tiles(p.bm, p.bn);
     p.ksplit = 1;
-    if (allow_split && !(a.flags & CF_ARGMAX) && t < num_cus && ksteps >= 8) {
-        int want = (int)((2LL * num_cus + t - 1) / t);
-        p.ksplit = std::max(1, std::min(want, ksteps / 4));
+    if (allow_split && !(a.flags & CF_ARGMAX) && t * 2 <= num_cus && ksteps >= 16) {
+        int want = (int)((num_cus + t - 1) / t);
+        p.ksplit = std::max(1, std::min(want, ksteps / 8));
     }
-    // experiment hook (tools/conv_sweep.py): FID_CONV_FORCE="bm,bn,ksplit" overrides the heuristic
+    // experiment hook (tools): FID_CONV_FORCE="bm,bn,ksplit[,ns]" overrides the heuristic
     if (const char *f = getenv("FID_CONV_FORCE")) {
-        int bm = 0, bn = 0, ks = 0;
-        if (sscanf(f, "%d,%d,%d", &bm, &bn, &ks) == 3) {
-            const bool have = p.bk == 64 ? ((bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64))
-                                         : (bm == 128 && (bn == 128 || bn == 96 || bn == 64 || bn == 32));
+        int bm = 0, bn = 0, ks = 0, ns = 0;
+        const int n = sscanf(f, "%d,%d,%d,%d", &bm, &bn, &ks, &ns);
+        if (n >= 3) {
+            const bool have = p.gen == 2 ? dma_have(bm, bn, p.bk)
+                              : (p.bk == 64 ? ((bm == 128 && (bn == 128 || bn == 64)) || (bm == 64 && bn == 64))
+                                            : (bm == 128 && (bn == 128 || bn == 96 || bn == 64 || bn == 32)));
             if (have) { p.bm = bm; p.bn = bn; }
             if (ks >= 1 && allow_split && !(a.flags & CF_ARGMAX)) p.ksplit = std::max(1, std::min(ks, ksteps / 2));
+            if (n >= 4 && ns >= 3 && ns <= 4 && p.bk == 64) p.ns = ns;
         }
     }
     p.partial_bytes = p.ksplit > 1 ? (size_t)p.ksplit * a.M * a.Cout_p * 4 : 0;
     return p;
 }
 
+std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split) {
+    std::vector<ConvPlan> out;
+    if (conv_direct_applicable(a)) { ConvPlan d{}; d.gen = 0; d.ksplit = 1; out.push_back(d); }
+    const int bk = (a.Cin_p % 64 == 0) ? 64 : 32;
+    const int ksteps = a.kh * a.kw * (a.Cin_p / bk);
+    auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
+    auto add = [&](int gen, int bm, int bn, int ns) {
+        const int smallest = bk == 64 ? 64 : 32;
+        if (bn > smallest && bn >= 2 * ((a.Cout_p + 31) / 32 * 32)) return;   // mostly-empty column tile
+        if (bn == 32 && a.Cout_p > 32) return;
+        if (bn == 96 && a.Cout_p % 96 != 0) return;
+        ConvPlan p{};
+        p.gen = gen; p.bm = bm; p.bn = bn; p.bk = bk; p.ns = ns; p.ksplit = 1;
+        out.push_back(p);
+        const long long t = tiles(bm, bn);
+        if (allow_split && !(a.flags & CF_ARGMAX) && t < num_cus && ksteps >= 16) {
+            const int want = (int)((num_cus + t - 1) / t);
+            const int ks = std::max(1, std::min(want, ksteps / 8));
+            if (ks > 1) { p.ksplit = ks; out.push_back(p); }
+        }
+    };
+    if (bk == 64) {
+        for (int gen = 1; gen <= 2; gen++) {
+            add(gen, 128, 128, 4); add(gen, 128, 64, 4); add(gen, 64, 64, 4);
+        }
+        add(2, 128, 128, 3); add(2, 128, 64, 3); add(2, 64, 64, 3);
+    } else {
+        for (int gen = 1; gen <= 2; gen++) {
+            add(gen, 128, 128, 4); add(gen, 128, 96, 4); add(gen, 128, 64, 4); add(gen, 128, 32, 4);
+        }
+    }
+    if (out.empty()) out.push_back(conv_plan(a, num_cus, false));
+    for (auto &p : out) p.partial_bytes = p.ksplit > 1 ? (size_t)p.ksplit * a.M * a.Cout_p * 4 : 0;
+    return out;
+}
+
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
+    if (plan.gen == 0) return conv_direct_launch(ctx, a);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);
-    FID_REQUIRE(a.Cin_p % plan.bk == 0 && a.Cout_p % 4 == 0, "conv: channel padding (Cin_p=%d Cout_p=%d)", a.Cin_p, a.Cout_p);
+    FID_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 4 == 0, "conv: channel padding (Cin_p=%d Cout_p=%d)", a.Cin_p, a.Cout_p);
+    FID_REQUIRE(a.Cin_p % plan.bk == 0, "conv: Cin_p=%d not a multiple of BK=%d", a.Cin_p, plan.bk);
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB; lower the batch");
     a.nchunk = a.Cin_p / plan.bk;
-    a.ksteps = a.T * a.nchunk;
+    a.ksteps = cdiv(a.T * a.Cin_p, plan.bk);
     a.ksplit = plan.ksplit;
     a.ksteps_per_split = cdiv(a.ksteps, a.ksplit);
     a.ksplit = cdiv(a.ksteps, a.ksteps_per_split);
@@ -411,16 +653,33 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     a.tiles_n = cdiv(a.Cout_p, plan.bn);
     FID_REQUIRE(a.ksplit == 1 || a.partial, "conv: split-K without a partial buffer");
     int rc = FID_E_INVALID;
-    const int key = plan.bm * 1000000 + plan.bn * 1000 + plan.bk;
-    switch (key) {
-        case 128128064: rc = launch_cfg<128, 128, 64, 2, 2>(ctx, a); break;
-        case 128064064: rc = launch_cfg<128, 64, 64, 2, 2>(ctx, a); break;
-        case 64064064: rc = launch_cfg<64, 64, 64, 2, 2>(ctx, a); break;
-        case 128128032: rc = launch_cfg<128, 128, 32, 2, 2>(ctx, a); break;
-        case 128096032: rc = launch_cfg<128, 96, 32, 2, 2>(ctx, a); break;
-        case 128064032: rc = launch_cfg<128, 64, 32, 2, 2>(ctx, a); break;
-        case 128032032: rc = launch_cfg<128, 32, 32, 4, 1>(ctx, a); break;
-        default: set_error("conv: no kernel for tile %dx%dx%d", plan.bm, plan.bn, plan.bk); return FID_E_INVALID;
+    if (plan.gen == 2) {
+        const int key = (plan.bm * 1000 + plan.bn) * 1000 + plan.bk * 10 + plan.ns;
+        switch (key) {
+            case 128128644: rc = launch_dma<128, 128, 64, 4, 2, 2>(ctx, a); break;
+            case 128128643: rc = launch_dma<128, 128, 64, 3, 2, 2>(ctx, a); break;
+            case 128064644: rc = launch_dma<128, 64, 64, 4, 2, 2>(ctx, a); break;
+            case 128064643: rc = launch_dma<128, 64, 64, 3, 2, 2>(ctx, a); break;
+            case 64064644: rc = launch_dma<64, 64, 64, 4, 2, 2>(ctx, a); break;
+            case 64064643: rc = launch_dma<64, 64, 64, 3, 2, 2>(ctx, a); break;
+            case 128128324: rc = launch_dma<128, 128, 32, 4, 2, 2>(ctx, a); break;
+            case 128096324: rc = launch_dma<128, 96, 32, 4, 2, 2>(ctx, a); break;
+            case 128064324: rc = launch_dma<128, 64, 32, 4, 2, 2>(ctx, a); break;
+            case 128032324: rc = launch_dma<128, 32, 32, 4, 4, 1>(ctx, a); break;
+            default: set_error("conv: no DMA kernel for tile %dx%dx%d ns=%d", plan.bm, plan.bn, plan.bk, plan.ns); return FID_E_INVALID;
+        }
+    } else {
+        const int key = plan.bm * 1000000 + plan.bn * 1000 + plan.bk;
+        switch (key) {
+            case 128128064: rc = launch_cfg<128, 128, 64, 2, 2>(ctx, a); break;
+            case 128064064: rc = launch_cfg<128, 64, 64, 2, 2>(ctx, a); break;
+            case 64064064: rc = launch_cfg<64, 64, 64, 2, 2>(ctx, a); break;
+            case 128128032: rc = launch_cfg<128, 128, 32, 2, 2>(ctx, a); break;
+            case 128096032: rc = launch_cfg<128, 96, 32, 2, 2>(ctx, a); break;
+            case 128064032: rc = launch_cfg<128, 64, 32, 2, 2>(ctx, a); break;
+            case 128032032: rc = launch_cfg<128, 32, 32, 4, 1>(ctx, a); break;
+            default: set_error("conv: no kernel for tile %dx%dx%d", plan.bm, plan.bn, plan.bk); return FID_E_INVALID;
+        }
     }
     FID_TRY(rc);
     if (a.ksplit > 1) {

@@ -8,6 +8,8 @@
 // max_batch; weights are one packed blob.  Nothing is allocated on the steady-state path.
 #include "net.h"
 
+#include <map>
+
 struct fid_net {
     int n_ops = 0, n_tensors = 0, in_h = 0, in_w = 0, max_batch = 0;
     std::vector<int32_t> ops, tensors;
@@ -17,6 +19,10 @@ struct fid_net {
     std::vector<size_t> slot_bytes_per_image;
     double macs_per_image = 0;
     int sub_batch = 0;   // images per depth-first pass (0 = whole batch)
+    // autotuned kernel choice per conv op and batch size: tuned[op][batch]
+    std::vector<std::map<int, fid::ConvPlan>> tuned;
+    int autotune = 1;
+    size_t partial_cap = 0;
     hipEvent_t *prof_events = nullptr;
     int n_prof_events = 0;
 };
@@ -199,12 +205,47 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             }
             a.in_bytes = (unsigned)((size_t)batch * src.H * src.W * src.Cp * 2);
             a.w_bytes = (unsigned)op[W_WBYTES];
-            if (conv_direct_applicable(a)) {
-                FID_TRY(conv_direct_launch(ctx, a));
-                break;
-            }
-            const ConvPlan plan = conv_plan(a, ctx->num_cus, partial_ws != nullptr);
             a.partial = (float *)partial_ws;
+            ConvPlan plan;
+            auto &cache = net->tuned[oi];
+            auto it = cache.find(batch);
+            if (it != cache.end()) {
+                plan = it->second;
+            } else if (net->autotune && partial_ws) {
+                // first time this op runs at this batch size: time every candidate kernel on the real
+                // operands (the op is idempotent) and keep the fastest; a split-K plan must win by 10 %
+                // to be preferred (its summation order differs from the unsplit kernels)
+                const std::vector<ConvPlan> cands = conv_candidates(a, ctx->num_cus, true);
+                hipEvent_t e0, e1;
+                FID_HIP(hipEventCreate(&e0));
+                FID_HIP(hipEventCreate(&e1));
+                float best = 1e30f;
+                plan = cands[0];
+                for (const ConvPlan &c : cands) {
+                    if (c.partial_bytes > net->partial_cap) continue;
+                    float tmin = 1e30f;
+                    for (int rep = 0; rep < 3; rep++) {
+                        FID_HIP(hipEventRecord(e0, ctx->stream));
+                        FID_TRY(conv_launch(ctx, a, c));
+                        FID_HIP(hipEventRecord(e1, ctx->stream));
+                        FID_HIP(hipEventSynchronize(e1));
+                        float ms = 0;
+                        FID_HIP(hipEventElapsedTime(&ms, e0, e1));
+                        if (rep > 0) tmin = std::min(tmin, ms);
+                    }
+                    const float score = c.ksplit > 1 ? tmin * 1.1f : tmin;
+                    if (score < best) { best = score; plan = c; }
+                }
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+                cache[batch] = plan;
+                if (getenv("FID_TUNE_LOG"))
+                    fprintf(stderr, "[tune] op %d M=%d Cin_p=%d Cout_p=%d k=%d s=%d -> gen %d tile %dx%dx%d ns %d split %d (%.1f us)\n", oi, a.M,
+                            a.Cin_p, a.Cout_p, a.kh, a.stride, plan.gen, plan.bm, plan.bn, plan.bk, plan.ns, plan.ksplit, best * 1e3f);
+            } else {
+                plan = conv_direct_applicable(a) ? ConvPlan{} : conv_plan(a, ctx->num_cus, partial_ws != nullptr);
+                if (conv_direct_applicable(a)) { plan.gen = 0; plan.ksplit = 1; }
+            }
             FID_TRY(conv_launch(ctx, a, plan));
             break;
         }
@@ -241,8 +282,12 @@ size_t partial_need(fid_ctx *ctx, fid_net *net, int batch) {
         a.Cin_p = src.Cp; a.Cout_p = dst.Cp; a.kh = op[W_KH]; a.kw = op[W_KW];
         a.M = batch * dst.H * dst.W; a.flags = op[W_FLAGS];
         need = std::max(need, conv_plan(a, ctx->num_cus, true).partial_bytes);
+        if (net->autotune) {
+            a.H = src.H; a.W = src.W; a.Ho = dst.H; a.Wo = dst.W; a.stride = op[W_STRIDE]; a.pad = op[W_PAD]; a.w_rows = op[W_WROWS];
+            for (const ConvPlan &c : conv_candidates(a, ctx->num_cus, true)) need = std::max(need, c.partial_bytes);
+        }
     }
-    return need;
+    return std::max<size_t>(need, 256);
 }
 
 int run_all(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float *op_ms) {
@@ -253,6 +298,7 @@ int run_all(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float 
     const int sbq = (!op_ms && net->sub_batch > 0) ? std::min(net->sub_batch, batch) : batch;
     const size_t need = std::max(partial_need(ctx, net, sbq), partial_need(ctx, net, batch % sbq ? batch % sbq : sbq));
     if (need) FID_TRY(get_scratch(ctx, 1, need, &partial_ws));
+    net->partial_cap = need;
     if (op_ms) {
         if (net->n_prof_events < net->n_ops + 1) {
             net->prof_events = new hipEvent_t[net->n_ops + 1];
@@ -344,6 +390,8 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
     net->blob_bytes = blob_bytes;
     FID_HIP(hipMemcpy(net->blob, blob, blob_bytes, hipMemcpyHostToDevice));
     if (const char *e = getenv("FID_SUB_BATCH")) net->sub_batch = atoi(e);
+    if (const char *e = getenv("FID_AUTOTUNE")) net->autotune = atoi(e);
+    net->tuned.resize(n_ops);
     *out = net;
     return FID_OK;
 }
