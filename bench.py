@@ -71,7 +71,7 @@ def build(ctx, batch, F, gallery_size, calib_frames):
 
 def mfma_roofline(pipe, frames_dev, batch, F):
     """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs."""
-    from scrfd_arcface_facerecognition_amd.lower import OP_CONV
+    from scrfd_arcface_facerecognition_amd.lower import OP_CONV, OP_STEMFUSED
     tot_ms, tot_flop, launches, per_net = 0.0, 0.0, 0, {}
     for name, cn, imgs, n in (("scrfd_10g", pipe.det, frames_dev, batch), ("arcface_r50", pipe.rec, pipe.crops, batch * F)):
         best = None
@@ -79,10 +79,11 @@ def mfma_roofline(pipe, frames_dev, batch, F):
             ms = cn.run_profiled(imgs, n)
             best = ms if best is None else np.minimum(best, ms)
         t, fl, k = 0.0, 0.0, 0
-        for oi, node in enumerate(cn.net.nodes):
-            if int(cn.low.ops[oi, 0]) != OP_CONV:
+        by_name = {nd.name: nd for nd in cn.net.nodes}
+        for oi, names in enumerate(cn.low.op_nodes):
+            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEMFUSED):
                 continue
-            macs = node_macs(cn.net, node)
+            macs = sum(node_macs(cn.net, by_name[nm]) for nm in names)
             t += float(best[oi]); fl += 2.0 * macs * n; k += 1
         per_net[name] = {"ms": round(t, 4), "tflops": round(fl / t / 1e9, 1), "launches": k,
                          "net_ms_all_ops": round(float(best.sum()), 4)}
@@ -90,8 +91,8 @@ def mfma_roofline(pipe, frames_dev, batch, F):
     ach = tot_flop / tot_ms / 1e9
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP16_TFLOPS, 4), "traffic": None,
-            "kernel": "MFMA conv kernels of one step: conv_mfma_kernel<*> / conv_mfma_dma_kernel<*> / conv3x3_direct<*> "
-                      "(per layer the autotuner's pick)", "launches": launches,
+            "kernel": "MFMA conv kernels of one step: conv_mfma_kernel<*> / conv_mfma_dma_kernel<*> / conv3x3_direct<*> / "
+                      "scrfd_stem_fused<*> (per layer the autotuner's pick)", "launches": launches,
             "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2), "gflop_per_step": round(tot_flop / 1e9, 1),
             "per_net": per_net}
 

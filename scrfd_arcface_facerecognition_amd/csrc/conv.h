@@ -49,4 +49,8 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan);
 bool conv_direct_applicable(const ConvArgs &a);
 int conv_direct_launch(fid_ctx *ctx, const ConvArgs &a);
 
+// stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
+int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,
+                      const float *b1, const void *w2, const float *b2, void *out, int C2p);
+
 }  // namespace fid

@@ -4,7 +4,7 @@
 
 namespace fid {
 
-enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4 };
+enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5 };
 
 // int32 word indices inside one op record (FID_OP_WORDS = 32 words)
 enum : int {
@@ -27,6 +27,9 @@ enum : int {
     W_SOFF = 16,   // PReLU slope table offset or -1
     W_WROWS = 17,  // rows (output channels) present in the packed weights
     W_GROUPS = 18, // 1, or cin for depthwise
+    // OP_STEMFUSED (stem_fused.hip): blob offsets of the three convs' packed weights / biases
+    W_F_W0 = 20, W_F_B0 = 21, W_F_W1 = 22, W_F_B1 = 23, W_F_W2 = 24, W_F_B2 = 25,
+    W_F_MACS_LO = 26, W_F_MACS_HI = 27,   // algorithmic MACs per image of the fused group (cost accounting)
 };
 
 // int32 word indices of one tensor record (FID_TENSOR_WORDS = 8 words)

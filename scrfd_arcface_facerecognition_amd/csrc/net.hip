@@ -249,6 +249,12 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             FID_TRY(conv_launch(ctx, a, plan));
             break;
         }
+        case OP_STEMFUSED: {
+            FID_TRY(stem_fused_launch(ctx, images, batch, net->in_h, net->in_w, blob + op[W_F_W0], (const float *)(blob + op[W_F_B0]),
+                                      blob + op[W_F_W1], (const float *)(blob + op[W_F_B1]), blob + op[W_F_W2],
+                                      (const float *)(blob + op[W_F_B2]), dst.ptr, dst.Cp));
+            break;
+        }
         case OP_MAXPOOL: {
             const TensorView src = view(net, op[W_SRC], first);
             const long long total = (long long)batch * dst.H * dst.W * (dst.Cp / 8);
@@ -366,13 +372,15 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
         const bool ok = op[W_DST] >= 0 && op[W_DST] < n_tensors && op[W_SRC] >= -1 && op[W_SRC] < n_tensors &&
                         op[W_RES] >= -1 && op[W_RES] < n_tensors && op[W_WOFF] >= -1 &&
                         (op[W_WOFF] < 0 || (size_t)op[W_WOFF] + (size_t)op[W_WBYTES] <= blob_bytes) &&
-                        (op[W_TYPE] == OP_STEM) == (op[W_SRC] == -1);
+                        (op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_STEMFUSED) == (op[W_SRC] == -1);
         if (!ok) {
             delete net;
             set_error("op %d: bad record", oi);
             return FID_E_INVALID;
         }
         const int32_t *dt = &net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS];
+        if (op[W_TYPE] == OP_STEMFUSED)
+            net->macs_per_image += (double)(((unsigned long long)(unsigned)op[W_F_MACS_HI] << 32) | (unsigned)op[W_F_MACS_LO]);
         if (op[W_TYPE] == OP_CONV || op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_DWCONV)
             net->macs_per_image += (double)dt[T_H] * dt[T_W] * op[W_COUT] * (op[W_CIN] / std::max(1, op[W_GROUPS])) * op[W_KH] * op[W_KW];
     }

@@ -26,7 +26,7 @@ import numpy as np
 from .archs import BN_EPS, Net, infer_shapes
 
 OP_WORDS, TENSOR_WORDS = 32, 8
-OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV = 1, 2, 3, 4
+OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED = 1, 2, 3, 4, 5
 ACT = {"none": 0, "relu": 1, "prelu": 2}
 CF_RES_UP2, CF_BORDER, CF_OUT_F32 = 1, 2, 4
 CPAD = 32
@@ -68,10 +68,12 @@ class Lowered:
         self.blob: bytes = b""
         self.tensor_id: Dict[str, int] = {}
         self.op_names: List[str] = []
+        self.op_nodes: List[List[str]] = []
         self.outputs: List[str] = []
         self.in_hw = (0, 0)
         self.macs = 0
         self.heads: Dict[str, dict] = {}     # DetHead name -> channel layout of the fused tensor
+        self.fused_groups: Dict[str, list] = {}   # fused op name -> graph nodes it covers
 
 
 def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
@@ -79,6 +81,7 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
     blob = _Blob()
     ops: List[List[int]] = []
     op_names: List[str] = []
+    op_nodes: List[List[str]] = []        # graph nodes each op covers (several for fused ops)
     tensors: List[List[int]] = []
     tid: Dict[str, int] = {}
     out = Lowered()
@@ -100,6 +103,7 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             rec[idx[k]] = int(v)
         ops.append(rec)
         op_names.append(name)
+        op_nodes.append([name])
 
     def pack_weights(W4, cin_p, cout_p):
         """[cout, cin, kh, kw] float64 -> fp16 [cout_p][kh*kw][cin_p]"""
@@ -116,7 +120,59 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
         o[: len(vec)] = vec
         return o
 
-    for n in net.nodes:
+    def folded(n):
+        """conv weights/bias with the trailing BatchNorm folded in (float64)"""
+        W = P[n.wname + ".weight"].astype(np.float64)
+        b = P[n.wname + ".bias"].astype(np.float64) if n.bias else np.zeros(n.cout)
+        if n.post_bn:
+            a2, b2 = _bn_affine(P, n.wname + ".post_bn")
+            W = W * a2[:, None, None, None]
+            b = b * a2 + b2
+        return W, b
+
+    # ---- SCRFD deep stem (conv/s2 - conv - conv - maxpool, all ReLU): one fused kernel (csrc/stem_fused.hip) ----
+    import os
+    fused_upto = 0
+    nd = net.nodes
+    if (len(nd) >= 4 and not os.environ.get("FID_NO_STEM_FUSE") and nd[0].kind == "conv" and nd[0].src == "input"
+            and all(x.kind == "conv" and x.k == 3 and x.pad == 1 and x.groups == 1 and x.act == "relu" and not x.pre_bn
+                    and x.res is None and not x.pre_avgpool for x in nd[0:3])
+            and nd[0].stride == 2 and nd[1].stride == 1 and nd[2].stride == 1 and nd[1].src == nd[0].name
+            and nd[2].src == nd[1].name and nd[3].kind == "maxpool" and nd[3].src == nd[2].name
+            and (nd[3].k, nd[3].stride, nd[3].pad) == (3, 2, 1) and nd[0].cout <= 32 and nd[1].cout <= 32
+            and nd[2].cout <= 64 and net.in_hw[0] % 4 == 0 and net.in_hw[1] % 4 == 0
+            and not any(getattr(x, "src", None) in (nd[0].name, nd[1].name, nd[2].name) or getattr(x, "res", None) in
+                        (nd[0].name, nd[1].name, nd[2].name) for x in nd[4:])
+            and not any(o in (nd[0].name, nd[1].name, nd[2].name) for o in net.outputs)):
+        c0, c1, c2, pool = nd[0], nd[1], nd[2], nd[3]
+        W0, b0 = folded(c0)
+        W1, b1 = folded(c1)
+        W2, b2 = folded(c2)
+        w0 = np.zeros((32, 32), dtype=np.float32)                      # [co][k = (dy*3+dx)*3 + c_bgr]
+        w0[: c0.cout, :27] = (W0[:, ::-1] * (net.in_scale / 2.0)).transpose(0, 2, 3, 1).reshape(c0.cout, 27)
+        c2p = _rup(c2.cout, CPAD)
+        offs = [blob.add(w0.astype(np.float16))[0], blob.add(padded(b0, 32))[0],
+                blob.add(pack_weights(W1, 32, 32))[0], blob.add(padded(b1, 32))[0],
+                blob.add(pack_weights(W2, 32, c2p))[0], blob.add(padded(b2, c2p))[0]]
+        _, hp, wp = shp[pool.name]
+        dst = new_tensor(pool.name, c2.cout, hp, wp)
+        rec = [0] * OP_WORDS
+        rec[0], rec[1], rec[2], rec[3] = OP_STEMFUSED, -1, dst, -1
+        rec[4] = rec[5] = 3
+        rec[13] = rec[15] = rec[16] = -1
+        rec[18] = 1
+        rec[20:26] = offs
+        macs = sum(shp[x.name][1] * shp[x.name][2] * x.cout * x.cin * 9 for x in (c0, c1, c2))
+        rec[26], rec[27] = macs & 0xFFFFFFFF, macs >> 32
+        if rec[26] >= 2 ** 31:
+            rec[26] -= 2 ** 32
+        ops.append(rec)
+        op_names.append("stem.fused")
+        op_nodes.append([c0.name, c1.name, c2.name, pool.name])
+        out.fused_groups = {"stem.fused": [c0.name, c1.name, c2.name, pool.name]}
+        fused_upto = 4
+
+    for n in net.nodes[fused_upto:]:
         if n.kind == "conv" and n.src == "input":
             assert n.k == 3 and n.pad == 1 and n.groups == 1 and not n.pre_bn and n.res is None
             cout, (_, ho, wo) = n.cout, shp[n.name]
@@ -305,6 +361,7 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
     out.blob = blob.bytes()
     out.tensor_id = tid
     out.op_names = op_names
+    out.op_nodes = op_nodes
     out.outputs = list(net.outputs)
     out.in_hw = net.in_hw
     return out

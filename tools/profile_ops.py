@@ -24,13 +24,15 @@ for _ in range(5):
     ms = cn.run_profiled(imgs, batch)
     best = ms if best is None else np.minimum(best, ms)
 shp = archs.infer_shapes(net)
+by_name = {nd.name: nd for nd in net.nodes}
 print(f"{arch} batch {batch}: total {best.sum():.3f} ms")
 print(f"{'op':28s} {'type':4s} {'out CxHxW':>14s} {'k':>2s} {'s':>2s} {'GFLOP':>8s} {'us':>8s} {'TFLOP/s':>8s}")
-for oi, node in enumerate(net.nodes):
+for oi, names in enumerate(cn.low.op_nodes):
     t = int(cn.low.ops[oi, 0])
-    fl = 2.0 * node_macs(net, node) * batch
+    fl = 2.0 * sum(node_macs(net, by_name[nm]) for nm in names) * batch
+    node = by_name[names[-1]]
     c, h, w = shp[node.name]
     k = getattr(node, "k", 0)
     s = getattr(node, "stride", 0)
-    print(f"{node.name:28s} {t:4d} {f'{c}x{h}x{w}':>14s} {k:2d} {s:2d} {fl / 1e9:8.2f} {best[oi] * 1e3:8.1f} "
+    print(f"{cn.low.op_names[oi]:28s} {t:4d} {f'{c}x{h}x{w}':>14s} {k:2d} {s:2d} {fl / 1e9:8.2f} {best[oi] * 1e3:8.1f} "
           f"{fl / best[oi] / 1e9 if best[oi] > 0 else 0:8.1f}")
