@@ -87,40 +87,50 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
     if (tid == 0) sIn[INP_HALFS] = (_Float16)0.f;       // the "k >= 27" / padding element
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    // ---- input patch prefetch: thread owns patch pixels tid + 512*i ----
-    constexpr int PPT = (RI * RI + 511) / 512;            // 4
-    uint8_t pre[PPT][3];
+    // ---- input patch prefetch: aligned dwords of the frame rows (3 per thread) instead of single bytes.
+    // A patch row starts at frame byte (32*tx - 7)*3 = 96*tx - 21; the dword-aligned window [96*tx - 24, +132)
+    // covers it (the frame width is a multiple of 4, so rows are dword aligned).  When the registers are
+    // committed each byte becomes the exact integer 2p-255 as fp16, or 0 where the pixel lies outside the
+    // frame (the blob's zero padding; a real pixel 0 maps to -255, so validity comes from coordinates).
+    constexpr int DROW = 33;                              // dwords per patch row
+    constexpr int NDW = RI * DROW;                        // 1419 dwords per patch
+    constexpr int DPT = (NDW + 511) / 512;                // 3
+    unsigned pre[DPT];
     auto prefetch = [&](int tile) {
         const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-        const int iy0 = 2 * (2 * ty * TP - 3) - 1, ix0 = 2 * (2 * tx * TP - 3) - 1;   // input origin of the 43x43 patch
+        const int iy0 = 2 * (2 * ty * TP - 3) - 1, bx0 = 96 * tx - 24;
         const uint8_t *base = a.img + (size_t)n * a.H * a.W * 3;
+        const int rowbytes = a.W * 3;
 #pragma unroll
-        for (int i = 0; i < PPT; i++) {
-            const int p = tid + 512 * i;
-            const int pr = p / RI, pc = p - pr * RI;
-            const int iy = iy0 + pr, ix = ix0 + pc;
-            const bool in = p < RI * RI && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const uint8_t *q = base + ((size_t)(in ? iy : 0) * a.W + (in ? ix : 0)) * 3;
-            pre[i][0] = in ? q[0] : (uint8_t)0; pre[i][1] = in ? q[1] : (uint8_t)0; pre[i][2] = in ? q[2] : (uint8_t)0;
-            // remember "outside" as an impossible pixel triple is unnecessary: outside must read as value 0
-            // AFTER the (2p - 255) map, so it is encoded by writing 0 directly below
-            if (!in) pre[i][0] = pre[i][1] = pre[i][2] = 0;
+        for (int i = 0; i < DPT; i++) {
+            const int d = tid + 512 * i;
+            const int pr = d / DROW, dc = d - pr * DROW;
+            const int iy = iy0 + pr, bx = bx0 + dc * 4;
+            const bool in = d < NDW && (unsigned)iy < (unsigned)a.H && bx >= 0 && bx + 4 <= rowbytes;
+            pre[i] = in ? *(const unsigned *)(base + (size_t)iy * rowbytes + bx) : 0u;
         }
     };
-    // validity has to be re-derived when the registers are committed (a real pixel 0 maps to -255, padding to 0)
     auto commit = [&](int tile) {
         const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
         const int iy0 = 2 * (2 * ty * TP - 3) - 1, ix0 = 2 * (2 * tx * TP - 3) - 1;
 #pragma unroll
-        for (int i = 0; i < PPT; i++) {
-            const int p = tid + 512 * i;
-            if (p < RI * RI) {
-                const int pr = p / RI, pc = p - pr * RI;
-                const bool in = (unsigned)(iy0 + pr) < (unsigned)a.H && (unsigned)(ix0 + pc) < (unsigned)a.W;
+        for (int i = 0; i < DPT; i++) {
+            const int d = tid + 512 * i;
+            if (d < NDW) {
+                const int pr = d / DROW, dc = d - pr * DROW;
+                const bool rin = (unsigned)(iy0 + pr) < (unsigned)a.H;
 #pragma unroll
-                for (int c = 0; c < 3; c++) sIn[p * 3 + c] = in ? (_Float16)(float)(2 * (int)pre[i][c] - 255) : (_Float16)0.f;
+                for (int j = 0; j < 4; j++) {
+                    const int e = dc * 4 + j - 3;          // element (pixel*3 + channel) inside the patch row
+                    if (e >= 0 && e < RI * 3) {
+                        const int pc = e / 3;
+                        const bool in = rin && (unsigned)(ix0 + pc) < (unsigned)a.W;
+                        const int v = (pre[i] >> (8 * j)) & 0xFF;
+                        sIn[pr * (RI * 3) + e] = in ? (_Float16)(float)(2 * v - 255) : (_Float16)0.f;
+                    }
+                }
             }
         }
     };
@@ -150,6 +160,7 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
         __syncthreads();
 
         // ---------------- S1: conv0, K = 27 (padded 32), stride 2, C0P outputs ----------------
+        if (!(a.ablate & 1))
         if (!(a.ablate & 1))
         for (int sub = wave; sub < (N0 + 15) / 16; sub += 8) {
             const int q = min(sub * 16 + frow, N0 - 1);
