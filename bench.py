@@ -89,8 +89,14 @@ def mfma_roofline(pipe, frames_dev, batch, F):
                          "net_ms_all_ops": round(float(best.sum()), 4)}
         tot_ms += t; tot_flop += fl; launches += k
     ach = tot_flop / tot_ms / 1e9
+    traffic = None       # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        traffic = round(pmc["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        pass
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP16_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
             "kernel": "MFMA conv kernels of one step: conv_mfma_kernel<*> / conv_mfma_dma_kernel<*> / conv3x3_direct<*> / "
                       "scrfd_stem_fused<*> (per layer the autotuner's pick)", "launches": launches,
             "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2), "gflop_per_step": round(tot_flop / 1e9, 1),
