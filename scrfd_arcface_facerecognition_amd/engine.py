@@ -110,13 +110,8 @@ def resolve_model(model_path: str, in_hw=None):
         net = ARCHS[arch](in_hw) if in_hw else ARCHS[arch]()
         return net, {k: z[k] for k in z.files if k != "__arch__"}
     if model_path.endswith(".onnx"):
-        from .onnx_reader import load_onnx_params
-        base = os.path.splitext(os.path.basename(model_path))[0]
-        arch = ONNX_BASENAMES.get(base)
-        if arch is None:
-            raise ValueError(f"cannot tell the architecture of {model_path}; expected one of {sorted(ONNX_BASENAMES)}")
-        net = ARCHS[arch](in_hw) if in_hw else ARCHS[arch]()
-        return net, load_onnx_params(model_path, net)
+        from .onnx_reader import load_onnx_model
+        return load_onnx_model(model_path, in_hw)
     raise ValueError(f"unsupported model file {model_path}")
 
 
