@@ -154,6 +154,15 @@ int fid_gallery_destroy(fid_ctx *ctx, fid_gallery *g);
 int fid_match(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, float thresh,
               int32_t *idx_dev, float *score_dev);
 int fid_gallery_info(fid_gallery *g, int *G, int *G_padded, int *dim);
+/* device address of the unit fp16 rows [G_padded, dim] (read-only view; owned by the gallery) */
+int fid_gallery_data(fid_gallery *g, void **unit_rows_dev);
+/* Vector-store use of the gallery -- the product layer's QdrantManager (reference qdrant_manager.py:91-212,
+ * smart_face_recognition.py:1619-1643): top-k cosine search with a score threshold (k in {1,2,4,5,8};
+ * results score-descending, index-ascending on ties, -1/0 beyond the last hit) and in-place upsert / delete
+ * of rows (an all-zero embedding deletes: a zero row can never match). */
+int fid_gallery_topk(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, int k, float thresh,
+                     int32_t *idx_dev, float *score_dev);
+int fid_gallery_set_rows(fid_ctx *ctx, fid_gallery *g, const int32_t *rows_host, const float *emb_host, int n);
 /* full cosine matrix fp32 [n, G_padded] (row stride = G_padded, a multiple of 32; columns >= G are
  * 0): tests / compute_similarity parity.  Caller-allocated device memory. */
 int fid_cosine_matrix(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n,

@@ -61,6 +61,9 @@ SIGNATURES = {
     "fid_gallery_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_void_pp]),
     "fid_gallery_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fid_gallery_info": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p]),
+    "fid_gallery_data": (C.c_int, [C.c_void_p, c_void_pp]),
+    "fid_gallery_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "fid_gallery_set_rows": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_void_p, C.c_int]),
     "fid_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "fid_cosine_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 }

@@ -29,6 +29,68 @@ __global__ void __launch_bounds__(256) l2norm_rows(const float *__restrict__ x, 
     for (int i = lane; i < dim; i += 64) out[(size_t)row * dim + i] = (_Float16)(r[i] / nrm);
 }
 
+// top-k per query row of a [n, ld] fp32 score matrix (k <= 8): one wavefront per row, each lane keeps the
+// best k of its strided share in registers (insertion), then k rounds of wave arg-max merge them.
+// Order: score descending, index ascending on ties; only scores > max(0, thresh) are reported.
+template <int K>
+__global__ void __launch_bounds__(256) topk_rows(const float *__restrict__ scores, int n, int G, int ld, float thresh,
+                                                 int *__restrict__ idx_out, float *__restrict__ score_out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float *r = scores + (size_t)row * ld;
+    float bs[K];
+    int bi[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) { bs[j] = -2.f; bi[j] = 0x7FFFFFFF; }
+    for (int i = lane; i < G; i += 64) {
+        float s = r[i];
+        int id = i;
+        if (s > bs[K - 1]) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const bool better = s > bs[j] || (s == bs[j] && id < bi[j]);
+                const float ts = bs[j]; const int ti = bi[j];
+                if (better) { bs[j] = s; bi[j] = id; s = ts; id = ti; }
+            }
+        }
+    }
+    const float floor_ = thresh > 0.f ? thresh : 0.f;
+    int head = 0;   // this lane's next unconsumed candidate is bs[head] (static indexing via select chain)
+    for (int t = 0; t < K; t++) {
+        float s = -2.f; int id = 0x7FFFFFFF;
+#pragma unroll
+        for (int j = 0; j < K; j++) if (j == head) { s = bs[j]; id = bi[j]; }
+        float ws = s; int wi = id;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(ws, o); const int oi = __shfl_xor(wi, o);
+            if (os > ws || (os == ws && oi < wi)) { ws = os; wi = oi; }
+        }
+        if (wi == id && ws == s) head++;            // the winning lane advances
+        if (lane == 0) {
+            const bool ok = ws > floor_;
+            idx_out[(size_t)row * K + t] = ok ? wi : -1;
+            score_out[(size_t)row * K + t] = ok ? ws : 0.f;
+        }
+    }
+}
+
+// normalise `n` host-provided rows and write them to arbitrary gallery rows (upsert); zero rows = deleted
+__global__ void __launch_bounds__(256) set_rows(const float *__restrict__ x, const int *__restrict__ rows, int n, int dim, int cap,
+                                                _Float16 *__restrict__ gal) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const int dst = rows[r];
+    if (dst < 0 || dst >= cap) return;
+    const float *src = x + (size_t)r * dim;
+    float ss = 0.f;
+    for (int i = lane; i < dim; i += 64) ss = fmaf(src[i], src[i], ss);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float nrm = sqrtf(ss);
+    for (int i = lane; i < dim; i += 64) gal[(size_t)dst * dim + i] = nrm > 0.f ? (_Float16)(src[i] / nrm) : (_Float16)0.f;
+}
+
 __global__ void __launch_bounds__(256) match_finalize(const unsigned long long *amax, int n, int G, float thresh, int *idx,
                                                       float *score) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,6 +174,12 @@ int fid_gallery_info(fid_gallery *g, int *G, int *G_padded, int *dim) {
     return FID_OK;
 }
 
+int fid_gallery_data(fid_gallery *g, void **unit_rows_dev) {
+    FID_REQUIRE(g && unit_rows_dev, "bad args");
+    *unit_rows_dev = g->unit_f16;
+    return FID_OK;
+}
+
 int fid_match(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, float thresh, int32_t *idx_dev, float *score_dev) {
     FID_REQUIRE(ctx && g && query_f16_dev && idx_dev && score_dev && n > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -122,6 +190,49 @@ int fid_match(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, fl
     hipLaunchKernelGGL(fid::match_finalize, dim3(fid::cdiv(n, 256)), dim3(256), 0, ctx->stream, (const unsigned long long *)ws, n, g->G,
                        thresh, idx_dev, score_dev);
     FID_HIP(hipGetLastError());
+    return FID_OK;
+}
+
+// Vector-store style use of the gallery (the product layer's QdrantManager.search_similar / add_embedding /
+// delete, reference qdrant_manager.py:91-212): top-k search with a score threshold, and in-place upserts.
+int fid_gallery_topk(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, int k, float thresh, int32_t *idx_dev,
+                     float *score_dev) {
+    FID_REQUIRE(ctx && g && query_f16_dev && idx_dev && score_dev && n > 0, "bad args");
+    FID_REQUIRE(k == 1 || k == 2 || k == 4 || k == 5 || k == 8, "k must be one of 1, 2, 4, 5, 8");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    // the score matrix is materialised per chunk of queries (<= 256 MiB) -- top-k needs every score once
+    const int chunk = std::max(1, (int)std::min<long long>(n, (256ll << 20) / ((long long)g->Gp * 4)));
+    void *ws;
+    FID_TRY(fid::get_scratch(ctx, 3, (size_t)chunk * g->Gp * 4, &ws));
+    for (int q0 = 0; q0 < n; q0 += chunk) {
+        const int m = std::min(chunk, n - q0);
+        const char *q = (const char *)query_f16_dev + (size_t)q0 * g->dim * 2;
+        FID_TRY(fid::gemm_vs_gallery(ctx, g, q, m, fid::CF_OUT_F32, ws, nullptr));
+        dim3 grid(fid::cdiv(m, 4));
+        int32_t *io = idx_dev + (size_t)q0 * k;
+        float *so = score_dev + (size_t)q0 * k;
+#define TOPK(KK) hipLaunchKernelGGL(fid::topk_rows<KK>, grid, dim3(256), 0, ctx->stream, (const float *)ws, m, g->G, g->Gp, thresh, io, so)
+        switch (k) { case 1: TOPK(1); break; case 2: TOPK(2); break; case 4: TOPK(4); break; case 5: TOPK(5); break; default: TOPK(8); }
+#undef TOPK
+    }
+    FID_HIP(hipGetLastError());
+    return FID_OK;
+}
+
+// rows_host[i] in [0, G): overwrite gallery row rows_host[i] with the unit vector of emb_host[i] (upsert);
+// an all-zero embedding deletes the row (a zero row can never match: a match needs a score > 0)
+int fid_gallery_set_rows(fid_ctx *ctx, fid_gallery *g, const int32_t *rows_host, const float *emb_host, int n) {
+    FID_REQUIRE(ctx && g && rows_host && emb_host && n > 0, "bad args");
+    for (int i = 0; i < n; i++) FID_REQUIRE(rows_host[i] >= 0 && rows_host[i] < g->G, "row %d outside the gallery (%d rows)", rows_host[i], g->G);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    void *ws;
+    const size_t eb = (size_t)n * g->dim * 4, rb = ((size_t)n * 4 + 255) & ~(size_t)255;
+    FID_TRY(fid::get_scratch(ctx, 3, eb + rb, &ws));
+    FID_HIP(hipMemcpyAsync(ws, rows_host, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    FID_HIP(hipMemcpyAsync((char *)ws + rb, emb_host, eb, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(fid::set_rows, dim3(fid::cdiv(n, 4)), dim3(256), 0, ctx->stream, (const float *)((char *)ws + rb), (const int *)ws, n,
+                       g->dim, g->G, (_Float16 *)g->unit_f16);
+    FID_HIP(hipStreamSynchronize(ctx->stream));   // the host buffers may be reused on return
     return FID_OK;
 }
 

@@ -213,3 +213,70 @@ class Gallery:
         if self.handle:
             self.ctx.lib.fid_gallery_destroy(self.ctx.handle, self.handle)
             self.handle = None
+
+
+class VectorGallery:
+    """An updatable gallery with top-k search: the role QdrantManager plays in the reference's product layer
+    (qdrant_manager.py:91-212: add_embedding / search_similar(limit, score_threshold) / delete_embedding),
+    kept in HBM as unit fp16 rows.  Ids are arbitrary hashables; rows freed by delete() are reused."""
+
+    def __init__(self, ctx: Context, dim: int = 512, capacity: int = 1024):
+        self.ctx, self.dim = ctx, int(dim)
+        self._gal = Gallery(ctx, np.zeros((int(capacity), dim), np.float32))
+        self.row_of: Dict[object, int] = {}
+        self.id_of: Dict[int, object] = {}
+        self._free = list(range(int(capacity) - 1, -1, -1))
+
+    def __len__(self):
+        return len(self.row_of)
+
+    def _grow(self):
+        old = self._gal
+        cap = old.G * 2
+        rows = self.ctx.borrow(_gallery_ptr(old), (old.Gp, self.dim), np.float16).download()[:old.G].astype(np.float32)
+        new = Gallery(self.ctx, np.concatenate([rows, np.zeros((cap - old.G, self.dim), np.float32)]))
+        self._free = list(range(cap - 1, old.G - 1, -1)) + self._free
+        old.close()
+        self._gal = new
+
+    def upsert(self, ids, embeddings):
+        emb = np.ascontiguousarray(embeddings, dtype=np.float32).reshape(len(ids), self.dim)
+        rows = []
+        for i in ids:
+            if i not in self.row_of:
+                if not self._free:
+                    self._grow()
+                r = self._free.pop()
+                self.row_of[i], self.id_of[r] = r, i
+            rows.append(self.row_of[i])
+        rows = np.asarray(rows, dtype=np.int32)
+        check(self.ctx.lib.fid_gallery_set_rows(self.ctx.handle, self._gal.handle, rows.ctypes.data_as(_lib.c_i32_p),
+                                                emb.ctypes.data_as(C.c_void_p), len(rows)))
+
+    def delete(self, ids):
+        rows = np.asarray([self.row_of.pop(i) for i in ids], dtype=np.int32)
+        for r in rows:
+            self.id_of.pop(int(r))
+            self._free.append(int(r))
+        zeros = np.zeros((len(rows), self.dim), np.float32)
+        check(self.ctx.lib.fid_gallery_set_rows(self.ctx.handle, self._gal.handle, rows.ctypes.data_as(_lib.c_i32_p),
+                                                zeros.ctypes.data_as(C.c_void_p), len(rows)))
+
+    def search(self, embeddings, k: int = 5, score_threshold: float = 0.0):
+        """-> per query a list of (id, score), best first (at most k, only scores > max(0, threshold))."""
+        emb = np.ascontiguousarray(embeddings, dtype=np.float32).reshape(-1, self.dim)
+        n = emb.shape[0]
+        e = self.ctx.to_device(emb)
+        q = self.ctx.empty((n, self.dim), np.float16)
+        check(self.ctx.lib.fid_l2_normalize_f16(self.ctx.handle, C.c_void_p(e.ptr), n, self.dim, C.c_void_p(q.ptr)))
+        idx, sc = self.ctx.empty((n, k), np.int32), self.ctx.empty((n, k), np.float32)
+        check(self.ctx.lib.fid_gallery_topk(self.ctx.handle, self._gal.handle, C.c_void_p(q.ptr), n, int(k), float(score_threshold),
+                                            C.c_void_p(idx.ptr), C.c_void_p(sc.ptr)))
+        I, S = idx.download(), sc.download()
+        return [[(self.id_of[int(j)], float(s)) for j, s in zip(I[r], S[r]) if j >= 0] for r in range(n)]
+
+
+def _gallery_ptr(gal: Gallery) -> int:
+    p = C.c_void_p()
+    check(gal.ctx.lib.fid_gallery_data(gal.handle, C.byref(p)))
+    return int(p.value)

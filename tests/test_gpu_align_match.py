@@ -145,3 +145,34 @@ def test_match_random_vs_oracle(ctx, n, G):
     margin = np.abs(np.sort(e @ gg.T, axis=1)[:, -1] - 0.4) > 2e-3     # decisions not within fp16 noise of the threshold
     assert np.array_equal(idx[margin], oi[margin])
     assert np.abs(sc[margin] - osim[margin]).max() < 1e-3
+
+
+def test_vector_gallery_topk_upsert_delete(ctx):
+    """top-k search + upsert/delete (the QdrantManager analogue) against a numpy reference."""
+    from scrfd_arcface_facerecognition_amd.engine import VectorGallery
+    rng = np.random.default_rng(21)
+    vg = VectorGallery(ctx, 512, capacity=64)
+    emb = {f"p{i}": rng.standard_normal(512).astype(np.float32) for i in range(150)}      # forces two capacity doublings
+    ids = list(emb)
+    vg.upsert(ids[:100], np.stack([emb[i] for i in ids[:100]]))
+    vg.upsert(ids[100:], np.stack([emb[i] for i in ids[100:]]))
+    vg.delete(ids[10:20])
+    emb["p3"] = rng.standard_normal(512).astype(np.float32)
+    vg.upsert(["p3"], emb["p3"][None])                                                    # overwrite in place
+    live = [i for i in ids if i not in ids[10:20]]
+    assert len(vg) == len(live) == 140
+    M = np.stack([emb[i] for i in live]); M /= np.linalg.norm(M, axis=1, keepdims=True)
+    queries = np.stack([emb["p3"] + 0.3 * rng.standard_normal(512), emb["p120"], emb["p15"], rng.standard_normal(512)]).astype(np.float32)
+    qn = queries / np.linalg.norm(queries, axis=1, keepdims=True)
+    true = qn @ M.T
+    for k in (1, 5, 8):
+        res = vg.search(queries, k=k, score_threshold=0.05)
+        for r, hits in enumerate(res):
+            order = np.argsort(-true[r])
+            want = [(live[j], true[r, j]) for j in order[:k] if true[r, j] > 0.05]
+            assert len(hits) == len(want), (k, r)
+            for (hid, hs), (wid, ws) in zip(hits, want):
+                assert abs(hs - ws) < 1e-3
+                assert hid == wid or abs(true[r, live.index(hid)] - ws) < 1e-3
+    assert vg.search(queries[:2], k=1)[0][0][0] == "p3" and vg.search(queries[:2], k=1)[1][0][0] == "p120"
+    assert all(h[0] != "p15" for h in vg.search(queries[2:3], k=8, score_threshold=0.0)[0])   # deleted id never returned
