@@ -604,6 +604,12 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
 std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split) {
     std::vector<ConvPlan> out;
     if (conv_direct_applicable(a)) { ConvPlan d{}; d.gen = 0; d.ksplit = 1; out.push_back(d); }
+    if (conv_chunked_applicable(a) && !getenv("FID_NO_CHUNKED")) {
+        ConvPlan d{};
+        d.gen = 3; d.ksplit = 1; d.bm = 256; d.bk = 32;
+        d.bn = 64; out.push_back(d);
+        if (a.Cout_p % 96 == 0) { d.bn = 96; out.push_back(d); }
+    }
     const int bk = (a.Cin_p % 64 == 0) ? 64 : 32;
     const int ksteps = a.kh * a.kw * (a.Cin_p / bk);
     auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
@@ -639,6 +645,7 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
 
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 0) return conv_direct_launch(ctx, a);
+    if (plan.gen == 3) return conv_chunked_launch(ctx, a, plan.bn);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);
     FID_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 4 == 0, "conv: channel padding (Cin_p=%d Cout_p=%d)", a.Cin_p, a.Cout_p);

@@ -1,0 +1,244 @@
+// Channel-chunked direct 3x3 / stride-1 convolution for the WIDE layers (96 ... 512 channels): the same
+// halo-patch idea as conv_direct.hip, for filter banks that do not fit in LDS.
+//
+// The implicit-GEMM kernels re-fetch every activation once per tap: a 128x128 tile streams 32 KB per 512
+// MFMA-cycles = 64 B/clk/CU, more than L2->LDS delivers (~29 B/clk/CU measured), so those layers sit at <= 45 %
+// of the matrix peak by construction.  Here a work item is one 16x16-pixel tile x CB output channels
+// (CB = 64 or 96); the K axis is walked in chunks of 32 input channels, and per chunk the workgroup fetches
+//     patch chunk   18x18 pixels x 32 ch          20.7 KB   (activations cross L2->LDS once, not 9 times)
+//     weight chunk  9 taps x CB couts x 32 ch   36.9 / 55.3 KB
+// by LDS-DMA into one of two buffers while the other one is multiplied: 9 taps x 4 x NI MFMAs per wave with no
+// barrier inside (one barrier per chunk).  8 waves = 4 pixel groups x 2 cout groups, so both waves of a SIMD
+// always have matrix work.  (item, chunk) pairs form one linear sequence per persistent workgroup: the first
+// chunk of the next item is already in flight while the last chunk of the current one is multiplied and its
+// tile is stored.
+// Traffic per 16x16x96 item with 96 input channels: 228 KB for 42 MFLOP (184 flop/B; implicit GEMM: 64).
+// Applicable to 3x3 / stride 1 / pad 1 with Cin_p % 32 == 0; the per-layer autotuner decides whether it wins
+// (small maps waste tile area: 14x14 -> 77 %, 20x20 -> 39 %).
+#include "epilogue.h"
+
+namespace fid {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0x7FFFFFF0u;
+constexpr int TH = 16, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;   // 324 patch pixels
+constexpr int CK = 32;                                               // input channels per chunk
+constexpr int PATCH_BLKS = (NPIX + 15) / 16;                         // 21 DMA blocks of 16 pixels x 64 B
+constexpr int PATCH_BYTES = PATCH_BLKS * 1024;
+
+__device__ __forceinline__ int swz64(int lin) { return (lin >> 1) & 3; }
+
+struct ChunkArgs {
+    const void *in;
+    const void *w;
+    const float *bias;
+    const float *slope;
+    const void *res;
+    void *out;
+    int H, W, B, Cin_p, Cout_p, w_rows;
+    int act, flags, nsig;
+    int res_Cp;
+    int tiles_x, tiles_y, n_tiles, n_cblk, n_items, n_chunks;
+    unsigned in_bytes, w_bytes;
+};
+
+template <int NI>   // couts per wave = NI*16; per workgroup CB = 2*NI*16
+__global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
+    constexpr int CB = 2 * NI * 16, MI = 4;
+    constexpr int W_BLKS = 9 * CB * 64 / 1024;          // weight-chunk DMA blocks (16 rows of 64 B each)
+    constexpr int W_BYTES = W_BLKS * 1024;
+    constexpr int BUF = W_BYTES + PATCH_BYTES;
+    constexpr int N_BLKS = W_BLKS + PATCH_BLKS;
+    constexpr int MAX_D = (N_BLKS + 7) / 8;             // DMA instructions per wave per chunk
+    static_assert(2 * BUF <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wg = wave & 3;           // cout group, pixel group
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+
+    // ---- per-lane constants of my DMA blocks: block j = wave + 8*k; j < W_BLKS -> weights, else patch ----
+    int d_a[MAX_D], d_b[MAX_D], d_c[MAX_D];              // weights: (row t*CB+co -> t, co), chunk ; patch: (py, px), chunk
+#pragma unroll
+    for (int k = 0; k < MAX_D; k++) {
+        const int j = wave + 8 * k;
+        const int row = (j < W_BLKS ? j : j - W_BLKS) * 16 + (lane >> 2);
+        const int chunk = ((lane & 3) ^ swz64(row)) * 8;
+        d_c[k] = chunk;
+        if (j < W_BLKS) {
+            d_a[k] = row / CB;                              // tap
+            d_b[k] = row - d_a[k] * CB;                     // cout inside the block
+        } else {
+            d_a[k] = row / PW;                              // patch row
+            d_b[k] = row - d_a[k] * PW;                     // patch column
+            if (j >= N_BLKS || row >= NPIX) d_a[k] = -100000;
+        }
+    }
+    auto issue = [&](int item, int chunk_k, int buf) {
+        const int tile = item / a.n_cblk, cb = item - tile * a.n_cblk;
+        const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1, co_base = cb * CB, c0 = chunk_k * CK;
+        char *dst = smem + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < MAX_D; k++) {
+            const int j = wave + 8 * k;
+            if (j < W_BLKS) {
+                const int co = co_base + d_b[k];
+                const unsigned vo = co < a.w_rows ? (unsigned)(((co * 9 + d_a[k]) * a.Cin_p + c0 + d_c[k]) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
+            } else if (j < N_BLKS) {
+                const int iy = y0 + d_a[k], ix = x0 + d_b[k];
+                const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + d_c[k]) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
+            }
+        }
+    };
+
+    // my items: blockIdx.x, + gridDim.x, ...; steps = (local item, chunk) linearised
+    const int my_items = blockIdx.x < a.n_items ? (a.n_items - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const int n_steps = my_items * a.n_chunks;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int lin0 = (wg * MI) * PW + frow;
+    EpiArgs ep{a.bias, a.slope, a.res, a.out, a.Cout_p, a.H, a.W, a.act, a.flags, a.nsig, a.H, a.W, a.res_Cp};
+
+    if (n_steps > 0) issue(blockIdx.x, 0, 0);
+    f32x4 acc[NI][MI];
+    int li = 0, ck = 0;                                   // local item index / chunk of the current step
+    for (int s = 0; s < n_steps; s++) {
+        const int buf = s & 1;
+        const int item = blockIdx.x + li * gridDim.x;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my DMAs of step s (the only ones outstanding) landed
+        __syncthreads();                                    // everyone's landed; everyone is done with buffer buf^1
+        {   // request step s+1 into the other buffer
+            int nli = li, nck = ck + 1;
+            if (nck == a.n_chunks) { nck = 0; nli++; }
+            if (s + 1 < n_steps) issue(blockIdx.x + nli * gridDim.x, nck, buf ^ 1);
+        }
+        if (ck == 0) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const char *sW = smem + buf * BUF, *sP = sW + W_BYTES;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int dy = t / 3, dx = t % 3;
+            half8 wf[NI], pf[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int row = t * CB + (grp * NI + ni) * 16 + frow;
+                wf[ni] = *(const half8 *)(sW + row * 64 + ((fq ^ swz64(row)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int lin = lin0 + (mi + dy) * PW + dx;
+                pf[mi] = *(const half8 *)(sP + lin * 64 + ((fq ^ swz64(lin)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (ck == a.n_chunks - 1) {
+            // ---- item finished: epilogue, transposed through this (now idle) buffer into whole-row stores ----
+            const int tile = item / a.n_cblk, cb = item - tile * a.n_cblk;
+            const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
+            const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+            const int co_w = cb * CB + grp * NI * 16;       // first cout of this wave
+            EpiPix px[MI];
+            int co0[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int oy = ty * TH + wg * MI + mi, ox = tx * TW + frow;
+                px[mi].valid = oy < a.H && ox < a.W;
+                px[mi].n = n; px[mi].oy = oy; px[mi].ox = ox;
+                px[mi].m = px[mi].valid ? ((long long)n * a.H + oy) * a.W + ox : 0;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) co0[ni] = co_w + ni * 16 + fq * 4;
+            if (a.flags & CF_OUT_F32) {
+                epilogue_tile<NI, MI>(ep, acc, px, co0);
+            } else {
+                constexpr int OROWB = NI * 32, OCPP = NI * 2, PPI = 64 / OCPP;
+                constexpr int OMASK = (OCPP & (OCPP - 1)) == 0 ? OCPP - 1 : 0;
+                ep_half4 hv[NI][MI];
+                epilogue_values<NI, MI>(ep, acc, px, co0, hv);
+                __syncthreads();                              // all waves are done reading this buffer's operands
+                char *sS = smem + buf * BUF + wave * (64 * OROWB);
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) {
+                        const int p = mi * 16 + frow, c = ni * 2 + (fq >> 1);
+                        *(ep_half4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4) + (fq & 1) * 8) = hv[ni][mi];
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int s2 = 0; s2 < (64 + PPI - 1) / PPI; s2++) {
+                    const int p = s2 * PPI + lane / OCPP, c = lane % OCPP;
+                    if (lane < PPI * OCPP && p < 64) {
+                        const u32x4 v = *(const u32x4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4));
+                        const int oy = ty * TH + wg * MI + (p >> 4), ox = tx * TW + (p & 15);
+                        if (oy < a.H && ox < a.W && co_w + c * 8 < a.Cout_p)
+                            *(u32x4 *)((char *)a.out + ((((size_t)n * a.H + oy) * a.W + ox) * a.Cout_p + co_w) * 2 + c * 16) = v;
+                    }
+                }
+            }
+        }
+        if (++ck == a.n_chunks) { ck = 0; li++; }
+    }
+}
+
+template <int NI>
+int launch_chunked(fid_ctx *ctx, const ChunkArgs &a) {
+    constexpr int CB = 2 * NI * 16;
+    constexpr size_t lds = 2 * ((size_t)9 * CB * 64 + PATCH_BYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_chunked<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int grid = std::min(a.n_items, ctx->num_cus);
+    hipLaunchKernelGGL((conv3x3_chunked<NI>), dim3(grid), dim3(512), lds, ctx->stream, a);
+    FID_HIP(hipGetLastError());
+    return FID_OK;
+}
+
+}  // namespace
+
+bool conv_chunked_applicable(const ConvArgs &a) {
+    return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Cin_p % 32 == 0 && a.Cin_p >= 64 && a.Cout_p >= 64 &&
+           a.w_rows == a.Cout_p && a.H == a.Ho && a.W == a.Wo && a.H >= 12 && a.W >= 12 && !(a.flags & (CF_RES_UP2 | CF_ARGMAX)) &&
+           (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo));
+}
+
+// cb: output channels per workgroup (64 or 96)
+int conv_chunked_launch(fid_ctx *ctx, const ConvArgs &c, int cb) {
+    ChunkArgs a{};
+    a.in = c.in; a.w = c.w; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
+    a.H = c.H; a.W = c.W; a.B = c.M / (c.Ho * c.Wo); a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p; a.w_rows = c.w_rows;
+    a.act = c.act; a.flags = c.flags; a.nsig = c.nsig; a.res_Cp = c.res_Cp;
+    a.tiles_x = cdiv(c.W, TW); a.tiles_y = cdiv(c.H, TH);
+    a.n_tiles = a.B * a.tiles_x * a.tiles_y;
+    a.n_cblk = cdiv(c.Cout_p, cb);
+    a.n_items = a.n_tiles * a.n_cblk;
+    a.n_chunks = c.Cin_p / CK;
+    a.in_bytes = c.in_bytes; a.w_bytes = c.w_bytes;
+    FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
+    if (cb == 64) return launch_chunked<2>(ctx, a);
+    if (cb == 96) return launch_chunked<3>(ctx, a);
+    set_error("chunked conv: cb=%d unsupported", cb);
+    return FID_E_INVALID;
+}
+
+}  // namespace fid

@@ -215,7 +215,13 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 // first time this op runs at this batch size: time every candidate kernel on the real
                 // operands (the op is idempotent) and keep the fastest; a split-K plan must win by 10 %
                 // to be preferred (its summation order differs from the unsplit kernels)
-                const std::vector<ConvPlan> cands = conv_candidates(a, ctx->num_cus, true);
+                std::vector<ConvPlan> cands = conv_candidates(a, ctx->num_cus, true);
+                if (const char *fg = getenv("FID_FORCE_GEN")) {      // tests: exercise one kernel family wherever it applies
+                    std::vector<ConvPlan> only;
+                    for (const ConvPlan &c : cands)
+                        if (c.gen == atoi(fg)) only.push_back(c);
+                    if (!only.empty()) cands = only;
+                }
                 hipEvent_t e0, e1;
                 FID_HIP(hipEventCreate(&e0));
                 FID_HIP(hipEventCreate(&e1));
