@@ -27,7 +27,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x7FFFFFF0u;
 constexpr int TH = 16, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;   // 324 patch pixels
 constexpr int CK = 32;                                               // input channels per chunk
-constexpr int PATCH_BLKS = (NPIX + 15) / 16;                         // 21 DMA blocks of 16 pixels x 64 B
+constexpr int PATCH_BLKS = 24;                                       // 21 DMA blocks of 16 pixels x 64 B, padded to 3 per wave
 constexpr int PATCH_BYTES = PATCH_BLKS * 1024;
 
 __device__ __forceinline__ int swz64(int lin) { return (lin >> 1) & 3; }
@@ -46,15 +46,23 @@ struct ChunkArgs {
     unsigned in_bytes, w_bytes;
 };
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_c() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int NI>   // couts per wave = NI*16; per workgroup CB = 2*NI*16
 __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
     constexpr int CB = 2 * NI * 16, MI = 4;
     constexpr int W_BLKS = 9 * CB * 64 / 1024;          // weight-chunk DMA blocks (16 rows of 64 B each)
     constexpr int W_BYTES = W_BLKS * 1024;
-    constexpr int BUF = W_BYTES + PATCH_BYTES;
-    constexpr int N_BLKS = W_BLKS + PATCH_BLKS;
-    constexpr int MAX_D = (N_BLKS + 7) / 8;             // DMA instructions per wave per chunk
-    static_assert(2 * BUF <= 160 * 1024, "LDS budget");
+    constexpr int MAX_W = (W_BLKS + 7) / 8;             // weight DMA instructions per wave per chunk
+    constexpr int MAX_P = PATCH_BLKS / 8;               // patch DMA instructions per wave per chunk (exactly 3)
+    // patch ring depth: patches (HBM / Infinity-Cache latency) are fetched TWO chunks ahead when LDS allows,
+    // weights (L2-hot: every workgroup of a cout block reads the same ones) one chunk ahead
+    constexpr int PD = (2 * W_BYTES + 3 * PATCH_BYTES <= 160 * 1024) ? 3 : 2;
+    constexpr int AHEAD = PD - 1;
+    static_assert(2 * W_BYTES + PD * PATCH_BYTES <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,43 +71,67 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
     const int tiles_per_img = a.tiles_x * a.tiles_y;
 
-    // ---- per-lane constants of my DMA blocks: block j = wave + 8*k; j < W_BLKS -> weights, else patch ----
-    int d_a[MAX_D], d_b[MAX_D], d_c[MAX_D];              // weights: (row t*CB+co -> t, co), chunk ; patch: (py, px), chunk
+    // LDS: [weights ring: 2 x W_BYTES][patch ring: PD x PATCH_BYTES]
+    char *sWr = smem, *sPr = smem + 2 * W_BYTES;
+    // ---- per-lane constants of my DMA blocks (block j = wave + 8*k of the weight / of the patch image) ----
+    int w_t[MAX_W], w_co[MAX_W], w_c[MAX_W];
 #pragma unroll
-    for (int k = 0; k < MAX_D; k++) {
-        const int j = wave + 8 * k;
-        const int row = (j < W_BLKS ? j : j - W_BLKS) * 16 + (lane >> 2);
-        const int chunk = ((lane & 3) ^ swz64(row)) * 8;
-        d_c[k] = chunk;
-        if (j < W_BLKS) {
-            d_a[k] = row / CB;                              // tap
-            d_b[k] = row - d_a[k] * CB;                     // cout inside the block
-        } else {
-            d_a[k] = row / PW;                              // patch row
-            d_b[k] = row - d_a[k] * PW;                     // patch column
-            if (j >= N_BLKS || row >= NPIX) d_a[k] = -100000;
-        }
+    for (int k = 0; k < MAX_W; k++) {
+        const int row = (wave + 8 * k) * 16 + (lane >> 2);
+        w_c[k] = ((lane & 3) ^ swz64(row)) * 8;
+        w_t[k] = row / CB;
+        w_co[k] = row - w_t[k] * CB;
     }
-    auto issue = [&](int item, int chunk_k, int buf) {
-        const int tile = item / a.n_cblk, cb = item - tile * a.n_cblk;
-        const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
-        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-        const int y0 = ty * TH - 1, x0 = tx * TW - 1, co_base = cb * CB, c0 = chunk_k * CK;
-        char *dst = smem + buf * BUF;
+    int p_y[MAX_P], p_x[MAX_P], p_c[MAX_P];
 #pragma unroll
-        for (int k = 0; k < MAX_D; k++) {
+    for (int k = 0; k < MAX_P; k++) {
+        const int row = (wave + 8 * k) * 16 + (lane >> 2);
+        p_c[k] = ((lane & 3) ^ swz64(row)) * 8;
+        p_y[k] = row / PW;
+        p_x[k] = row - p_y[k] * PW;
+        if (row >= NPIX) p_y[k] = -100000;                  // padding rows of the patch image: always read as 0
+    }
+    auto decode_item = [&](int item, int &n, int &ty, int &tx, int &cb) {
+        const int tile = item / a.n_cblk;
+        cb = item - tile * a.n_cblk;
+        n = tile / tiles_per_img;
+        const int r = tile - n * tiles_per_img;
+        ty = r / a.tiles_x; tx = r - ty * a.tiles_x;
+    };
+    auto issue_weights = [&](int item, int chunk_k, int slot) {
+        int n, ty, tx, cb;
+        decode_item(item, n, ty, tx, cb);
+        const int co_base = cb * CB, c0 = chunk_k * CK;
+        char *dst = sWr + slot * W_BYTES;
+#pragma unroll
+        for (int k = 0; k < MAX_W; k++) {
             const int j = wave + 8 * k;
             if (j < W_BLKS) {
-                const int co = co_base + d_b[k];
-                const unsigned vo = co < a.w_rows ? (unsigned)(((co * 9 + d_a[k]) * a.Cin_p + c0 + d_c[k]) * 2) : OOB;
+                const int co = co_base + w_co[k];
+                const unsigned vo = co < a.w_rows ? (unsigned)(((co * 9 + w_t[k]) * a.Cin_p + c0 + w_c[k]) * 2) : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
-            } else if (j < N_BLKS) {
-                const int iy = y0 + d_a[k], ix = x0 + d_b[k];
-                const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + d_c[k]) * 2) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
             }
         }
+    };
+    auto issue_patch = [&](int item, int chunk_k, int slot) {   // exactly MAX_P instructions per wave (vmcnt accounting)
+        int n, ty, tx, cb;
+        decode_item(item, n, ty, tx, cb);
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1, c0 = chunk_k * CK;
+        char *dst = sPr + slot * PATCH_BYTES;
+#pragma unroll
+        for (int k = 0; k < MAX_P; k++) {
+            const int j = wave + 8 * k;
+            const int iy = y0 + p_y[k], ix = x0 + p_x[k];
+            const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + p_c[k]) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+    // step s -> (item, chunk)
+    auto step_item = [&](int s, int &item, int &ck) {
+        const int li = s / a.n_chunks;
+        ck = s - li * a.n_chunks;
+        item = blockIdx.x + li * gridDim.x;
     };
 
     // my items: blockIdx.x, + gridDim.x, ...; steps = (local item, chunk) linearised
@@ -109,18 +141,35 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
     const int lin0 = (wg * MI) * PW + frow;
     EpiArgs ep{a.bias, a.slope, a.res, a.out, a.Cout_p, a.H, a.W, a.act, a.flags, a.nsig, a.H, a.W, a.res_Cp};
 
-    if (n_steps > 0) issue(blockIdx.x, 0, 0);
+    // prologue: weights of step 0, patches of steps 0 and 1 (issue order matters for the counted waits below:
+    // per step the weights of s+1 are issued BEFORE the patch of s+2)
+    if (n_steps > 0) {
+        issue_weights(blockIdx.x, 0, 0);
+        issue_patch(blockIdx.x, 0, 0);
+    }
+    if (AHEAD == 2 && n_steps > 1) {
+        int it1, ck1;
+        step_item(1, it1, ck1);
+        issue_patch(it1, ck1, 1);
+    }
     f32x4 acc[NI][MI];
     int li = 0, ck = 0;                                   // local item index / chunk of the current step
     for (int s = 0; s < n_steps; s++) {
-        const int buf = s & 1;
         const int item = blockIdx.x + li * gridDim.x;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my DMAs of step s (the only ones outstanding) landed
-        __syncthreads();                                    // everyone's landed; everyone is done with buffer buf^1
-        {   // request step s+1 into the other buffer
-            int nli = li, nck = ck + 1;
-            if (nck == a.n_chunks) { nck = 0; nli++; }
-            if (s + 1 < n_steps) issue(blockIdx.x + nli * gridDim.x, nck, buf ^ 1);
+        // outstanding, oldest first: [W(s), P(s) | P(s+1)] at s = 0, else [W(s) | P(s+1)] (P(s) was issued a step
+        // earlier, before W(s)); everything up to W(s) must have landed, only the newest patch may stay in flight
+        if (AHEAD == 2 && s + 1 < n_steps) wait_vmcnt_c<MAX_P>();
+        else wait_vmcnt_c<0>();
+        __syncthreads();                                    // everyone's landed; everyone is done with step s-1's buffers
+        if (s + 1 < n_steps) {
+            int it1, ck1;
+            step_item(s + 1, it1, ck1);
+            issue_weights(it1, ck1, (s + 1) & 1);
+        }
+        if (s + AHEAD < n_steps) {
+            int it2, ck2;
+            step_item(s + AHEAD, it2, ck2);
+            issue_patch(it2, ck2, (s + AHEAD) % PD);
         }
         if (ck == 0) {
 #pragma unroll
@@ -128,26 +177,34 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const char *sW = smem + buf * BUF, *sP = sW + W_BYTES;
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
+        const char *sW = sWr + (s & 1) * W_BYTES, *sP = sPr + (s % PD) * PATCH_BYTES;
+        // software-pipelined over the taps: the fragments of tap t+1 are requested before the MFMAs of tap t issue,
+        // so the LDS latency hides behind matrix work instead of stalling every group
+        half8 wf[2][NI], pf[2][MI];
+        auto load_tap = [&](int t, int set) {
             const int dy = t / 3, dx = t % 3;
-            half8 wf[NI], pf[MI];
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) {
                 const int row = t * CB + (grp * NI + ni) * 16 + frow;
-                wf[ni] = *(const half8 *)(sW + row * 64 + ((fq ^ swz64(row)) << 4));
+                wf[set][ni] = *(const half8 *)(sW + row * 64 + ((fq ^ swz64(row)) << 4));
             }
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) {
                 const int lin = lin0 + (mi + dy) * PW + dx;
-                pf[mi] = *(const half8 *)(sP + lin * 64 + ((fq ^ swz64(lin)) << 4));
+                pf[set][mi] = *(const half8 *)(sP + lin * 64 + ((fq ^ swz64(lin)) << 4));
             }
+        };
+        load_tap(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            if (t + 1 < 9) load_tap(t + 1, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this tap's MFMAs (hipcc sinks it otherwise)
 #pragma unroll
             for (int ni = 0; ni < NI; ni++)
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t & 1][ni], pf[t & 1][mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (ck == a.n_chunks - 1) {
             // ---- item finished: epilogue, transposed through this (now idle) buffer into whole-row stores ----
@@ -174,7 +231,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
                 ep_half4 hv[NI][MI];
                 epilogue_values<NI, MI>(ep, acc, px, co0, hv);
                 __syncthreads();                              // all waves are done reading this buffer's operands
-                char *sS = smem + buf * BUF + wave * (64 * OROWB);
+                char *sS = (char *)sW + wave * (64 * OROWB);     // this step's weight slot is idle now
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -202,7 +259,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
 template <int NI>
 int launch_chunked(fid_ctx *ctx, const ChunkArgs &a) {
     constexpr int CB = 2 * NI * 16;
-    constexpr size_t lds = 2 * ((size_t)9 * CB * 64 + PATCH_BYTES);
+    constexpr size_t wb = (size_t)9 * CB * 64;
+    constexpr size_t lds = 2 * wb + ((2 * wb + 3 * PATCH_BYTES <= 160 * 1024) ? 3 : 2) * PATCH_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         FID_HIP(hipFuncSetAttribute((const void *)conv3x3_chunked<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
