@@ -1,0 +1,76 @@
+"""GPU, BASELINE.json configs[1] at FULL size (SCRFD-10G + ArcFace-R50, 64 frames of 640x640, 1k gallery):
+size-independent properties instead of an oracle run (the fp32 CPU oracle needs ~4 s per frame pair here).
+  * determinism: the same batch twice -> bit-identical detections, embeddings, matches
+  * permutation equivariance: reversing the frame order reverses every per-frame result bit-exactly
+  * duplicated frames give identical rows
+  * NMS idempotence: the survivors of a frame survive a second NMS unchanged
+  * a gallery built from the batch's own embeddings matches every face to itself with cosine 1 (+-1e-3)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_size_properties():
+    from scrfd_arcface_facerecognition_amd import archs
+    from scrfd_arcface_facerecognition_amd._lib import Context, check
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
+    from scrfd_arcface_facerecognition_amd.pipeline import FacePipeline, calibrate_detector_bias
+    ctx = Context(0)
+    B, F = 64, 1
+    rng = np.random.default_rng(77)
+    frames = rng.integers(0, 256, (B, 640, 640, 3), dtype=np.uint8)
+    frames[5] = frames[4]                                             # a duplicated frame
+    det_net = archs.scrfd_10g((640, 640))
+    det_P, _ = calibrate_detector_bias(ctx, det_net, archs.synth_params(det_net, 0), frames[:8], target=48)
+    rec_net = archs.iresnet50()
+    rec_P = archs.synth_params(rec_net, 0)
+    det = CompiledNet(ctx, det_net, det_P, max_batch=B)
+    rec = CompiledNet(ctx, rec_net, rec_P, max_batch=B * F)
+    pipe = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=F)
+    gal0 = Gallery(ctx, rng.standard_normal((1000, 512)).astype(np.float32))
+
+    def run(fr):
+        pipe.run_step(ctx.to_device(fr), 640, 640, gal0, 0.05)
+        pipe.post.check()
+        return (pipe.post.counts.download()[:B].copy(), pipe.post.det.download()[:, :F].copy(),
+                pipe.post.kps.download()[:, :F].copy(), pipe.embeddings().copy(), pipe.idx.download().copy(),
+                pipe.score.download().copy())
+
+    a = run(frames)
+    b = run(frames)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)                                   # determinism
+    counts, dets, kps, emb, idx, score = a
+    assert (counts >= 1).all()                                        # calibrated detector: every frame yields a face
+    r = run(frames[::-1].copy())
+    for x, y in zip(a, r):
+        assert np.array_equal(x, y[::-1])                             # permutation equivariance
+    assert np.array_equal(dets[4], dets[5]) and np.array_equal(emb[4], emb[5]) and idx[4] == idx[5]
+    assert np.isfinite(emb).all() and np.abs(emb).max() < 6e4
+
+    # NMS idempotence on one frame's full detection list
+    pipe2 = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=F)
+    pipe2.F = 0
+    pipe2.detect(ctx.to_device(frames), 640, 640)                     # max_num = 0: all survivors
+    pipe2.post.check()
+    n0 = int(pipe2.post.counts.download()[0])
+    d0 = pipe2.post.det.download()[0, :n0]
+    assert n0 >= 1
+    dd = ctx.to_device(d0)
+    keep, cnt = ctx.empty((n0,), np.int32), ctx.empty((1,), np.int32)
+    check(ctx.lib.fid_nms(ctx.handle, C.c_void_p(dd.ptr), n0, 0.4, C.c_void_p(keep.ptr), C.c_void_p(cnt.ptr)))
+    assert int(cnt.download()[0]) == n0 and np.array_equal(keep.download()[:n0], np.arange(n0))
+
+    # self-gallery: every face matches itself
+    gal = Gallery(ctx, emb)
+    run(frames)                                                       # pipe.q = unit embeddings of the forward order again
+    pipe.match(gal, 0.5)
+    idx2, sc2 = pipe.idx.download(), pipe.score.download()
+    for i in range(B):
+        assert idx2[i] == i or np.array_equal(emb[idx2[i]], emb[i])    # duplicates: first index wins
+        assert abs(sc2[i] - 1.0) < 1e-3
+    assert idx2[5] == 4
+    ctx.close()
