@@ -230,7 +230,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 for (const ConvPlan &c : cands) {
                     if (c.partial_bytes > net->partial_cap) continue;
                     float tmin = 1e30f;
-                    for (int rep = 0; rep < 3; rep++) {
+                    for (int rep = 0; rep < 5; rep++) {
                         FID_HIP(hipEventRecord(e0, ctx->stream));
                         FID_TRY(conv_launch(ctx, a, c));
                         FID_HIP(hipEventRecord(e1, ctx->stream));
