@@ -49,8 +49,9 @@ struct StemArgs {
 __device__ __forceinline__ int swz64(int lin) { return (lin >> 1) & 3; }
 __device__ __forceinline__ int swz128(int lin) { return lin & 7; }
 
-template <int C2P>
-__global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
+template <int C2P, int NW>
+__global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemArgs a) {
+    constexpr int NT = NW * 64;   // threads per workgroup
     constexpr int INP_HALFS = RI * RI * 3;              // 5547, + 1 zero element
     constexpr int INP_BYTES = (INP_HALFS * 2 + 2 + 255) / 256 * 256;
     constexpr int O0_BYTES = ((N0 + 15) / 16 * 16) * 64;  // 448 rows
@@ -73,13 +74,13 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
     const int frow = lane & 15, fq = lane >> 4;
 
     // ---- weights -> LDS once (tap-major rows of 64 B, 16-byte chunks swizzled by row) ----
-    for (int i = tid; i < W0_BYTES / 16; i += 512) ((u32x4 *)sW0)[i] = ((const u32x4 *)a.w0)[i];
-    for (int i = tid; i < 9 * C1P * 4; i += 512) {        // 16-byte chunks: row = t*C1P + co, 4 per row
+    for (int i = tid; i < W0_BYTES / 16; i += NT) ((u32x4 *)sW0)[i] = ((const u32x4 *)a.w0)[i];
+    for (int i = tid; i < 9 * C1P * 4; i += NT) {        // 16-byte chunks: row = t*C1P + co, 4 per row
         const int row = i >> 2, slot = i & 3, t = row / C1P, co = row - t * C1P;
         const int chunk = slot ^ swz64(row);
         *(u32x4 *)(sW1 + row * 64 + slot * 16) = *(const u32x4 *)(a.w1 + ((co * 9 + t) * C0P + chunk * 8));
     }
-    for (int i = tid; i < 9 * C2P * 4; i += 512) {
+    for (int i = tid; i < 9 * C2P * 4; i += NT) {
         const int row = i >> 2, slot = i & 3, t = row / C2P, co = row - t * C2P;
         const int chunk = slot ^ swz64(row);
         *(u32x4 *)(sW2 + row * 64 + slot * 16) = *(const u32x4 *)(a.w2 + ((co * 9 + t) * C1P + chunk * 8));
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
     // frame (the blob's zero padding; a real pixel 0 maps to -255, so validity comes from coordinates).
     constexpr int DROW = 33;                              // dwords per patch row
     constexpr int NDW = RI * DROW;                        // 1419 dwords per patch
-    constexpr int DPT = (NDW + 511) / 512;                // 3
+    constexpr int DPT = (NDW + NT - 1) / NT;
     unsigned pre[DPT];
     auto prefetch = [&](int tile) {
         const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
         const int rowbytes = a.W * 3;
 #pragma unroll
         for (int i = 0; i < DPT; i++) {
-            const int d = tid + 512 * i;
+            const int d = tid + NT * i;
             const int pr = d / DROW, dc = d - pr * DROW;
             const int iy = iy0 + pr, bx = bx0 + dc * 4;
             const bool in = d < NDW && (unsigned)iy < (unsigned)a.H && bx >= 0 && bx + 4 <= rowbytes;
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
         const int iy0 = 2 * (2 * ty * TP - 3) - 1, ix0 = 2 * (2 * tx * TP - 3) - 1;
 #pragma unroll
         for (int i = 0; i < DPT; i++) {
-            const int d = tid + 512 * i;
+            const int d = tid + NT * i;
             if (d < NDW) {
                 const int pr = d / DROW, dc = d - pr * DROW;
                 const bool rin = (unsigned)(iy0 + pr) < (unsigned)a.H;
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
         // ---------------- S1: conv0, K = 27 (padded 32), stride 2, C0P outputs ----------------
         if (!(a.ablate & 1))
         if (!(a.ablate & 1))
-        for (int sub = wave; sub < (N0 + 15) / 16; sub += 8) {
+        for (int sub = wave; sub < (N0 + 15) / 16; sub += NW) {
             const int q = min(sub * 16 + frow, N0 - 1);
             const int y = q / R0, x = q - y * R0;
             const int base = (2 * y * RI + 2 * x) * 3;
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
         // ---------------- S2: conv1 3x3, C0P -> C1P on the 21x21 patch -> 19x19 ----------------
         if (!(a.ablate & 2)) {
             constexpr int NSUB = (N1 + 15) / 16;          // 23
-            constexpr int MI = (NSUB + 7) / 8;            // 3 subtiles per wave (waves 0..6), wave 7 gets the rest
+            constexpr int MI = (NSUB + NW - 1) / NW;      // subtiles per wave (contiguous)
             int lin0[MI], qd[MI];
             bool have[MI], inside[MI];
 #pragma unroll
@@ -247,13 +248,13 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
         // ---------------- S3: conv2 3x3, C1P -> C2P on the 19x19 patch -> 17x17 ----------------
         if (!(a.ablate & 4)) {
             constexpr int NSUB = (N2 + 15) / 16;          // 19
-            constexpr int MI = (NSUB + 7) / 8;            // 3
+            constexpr int MI = (NSUB + NW - 1) / NW;
             int lin0[MI], qd[MI];
             bool have[MI], inside[MI];
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) {
                 // subtiles dealt round-robin so that every wave gets 2 and three waves get a third
-                const int sub = wave + 8 * mi;
+                const int sub = wave + NW * mi;
                 have[mi] = sub < NSUB;
                 qd[mi] = sub * 16 + frow;
                 const int q = min(qd[mi], N2 - 1);
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
         // ---------------- S4: maxpool 3x3 / stride 2 (pad 1) -> 8x8 x C2P, 16 B per lane ----------------
         if (!(a.ablate & 8)) {
             constexpr int CPP = ROW2 / 16;                 // chunks per pixel (8 or 4)
-            for (int i = tid; i < TP * TP * CPP; i += 512) {
+            for (int i = tid; i < TP * TP * CPP; i += NT) {
                 const int pp = i / CPP, c = i - pp * CPP;
                 const int py = pp / TP, px = pp - py * TP;
                 const int gy = ty * TP + py, gx = tx * TP + px;
@@ -333,18 +334,18 @@ __global__ void __launch_bounds__(512, 2) scrfd_stem_fused(const StemArgs a) {
     }
 }
 
-template <int C2P>
+template <int C2P, int NW>
 int launch_stem(fid_ctx *ctx, const StemArgs &a) {
     constexpr int INP_BYTES = ((RI * RI * 3) * 2 + 2 + 255) / 256 * 256;
     constexpr size_t lds = INP_BYTES + ((N0 + 15) / 16 * 16) * 64 + ((N1 + 15) / 16 * 16) * 64 + ((N2 + 15) / 16 * 16) * (C2P * 2) +
                            32 * 64 + 9 * C1P * 64 + 9 * C2P * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)scrfd_stem_fused<C2P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FID_HIP(hipFuncSetAttribute((const void *)scrfd_stem_fused<C2P, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int grid = std::min(a.n_tiles, ctx->num_cus);
-    hipLaunchKernelGGL((scrfd_stem_fused<C2P>), dim3(grid), dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL((scrfd_stem_fused<C2P, NW>), dim3(grid), dim3(NW * 64), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
 }
@@ -362,8 +363,9 @@ int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, con
     a.tiles_x = cdiv(a.Wp, TP); a.tiles_y = cdiv(a.Hp, TP);
     a.n_tiles = B * a.tiles_x * a.tiles_y;
     if (const char *e = getenv("FID_STEM_ABLATE")) a.ablate = atoi(e);
-    if (C2p == 64) return launch_stem<64>(ctx, a);
-    if (C2p == 32) return launch_stem<32>(ctx, a);
+    const bool w16 = getenv("FID_STEM_W16") != nullptr;  // 16 waves were measured: 1.6x SLOWER (128-VGPR cap spills, costlier barriers)
+    if (C2p == 64) return w16 ? launch_stem<64, 16>(ctx, a) : launch_stem<64, 8>(ctx, a);
+    if (C2p == 32) return w16 ? launch_stem<32, 16>(ctx, a) : launch_stem<32, 8>(ctx, a);
     set_error("fused stem: C2p=%d unsupported", C2p);
     return FID_E_INVALID;
 }
