@@ -38,13 +38,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // weights by lower.py.  Zero padding pads the *normalised* blob, i.e. contributes exactly 0.
 // VALU kernel (K = 27 is too short for the matrix cores to matter: 0.3 % / 0.6 % of the net's MACs);
 // weights are wave-uniform -> scalar loads, one FMA per (tap, channel, cout).
-template <int CPW>
+template <int CPW, int SPLIT = 4>   // SPLIT waves share a group of 64 pixels, each computing CPW of the couts
 __global__ void __launch_bounds__(256) stem_conv3x3(const uint8_t *__restrict__ img, const float *__restrict__ w,
                                                     const float *__restrict__ bias, const float *__restrict__ slope,
                                                     _Float16 *__restrict__ out, int H, int W, int Ho, int Wo, int Cout_p,
                                                     int stride, int act, long long total_pix) {
-    const long long pix = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long pix = ((long long)blockIdx.x * (4 / SPLIT) + wv / SPLIT) * 64 + (threadIdx.x & 63);
+    const int cg = wv % SPLIT;
     if (pix >= total_pix) return;
     const int hw = Ho * Wo;
     const int n = (int)(pix / hw);
@@ -176,12 +177,18 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             const int cpw = dst.Cp / 4;
             const float *w = (const float *)(blob + op[W_WOFF]);
             dim3 grid((unsigned)cdiv64(total, 64));
+            static const int split = getenv("FID_STEM_SPLIT") ? atoi(getenv("FID_STEM_SPLIT")) : 2;   // measured on IResNet stem: 4 -> 107 us, 2 -> 91 us, 1 -> 102 us
 #define STEM(CPW) hipLaunchKernelGGL(stem_conv3x3<CPW>, grid, dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, dst.Cp, op[W_STRIDE], op[W_ACT], total)
-            if (cpw == 8) STEM(8);
+#define STEMS(CPW, SP) hipLaunchKernelGGL((stem_conv3x3<CPW, SP>), dim3((unsigned)cdiv64(total, 64 * (4 / SP))), dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, dst.Cp, op[W_STRIDE], op[W_ACT], total)
+            if (split == 1 && dst.Cp == 64) STEMS(64, 1);
+            else if (split == 2 && dst.Cp == 64) STEMS(32, 2);
+            else if (split == 1 && dst.Cp == 32) STEMS(32, 1);
+            else if (cpw == 8) STEM(8);
             else if (cpw == 16) STEM(16);
             else if (cpw == 32) STEM(32);
             else { set_error("stem: Cout_p=%d unsupported", dst.Cp); return FID_E_INVALID; }
 #undef STEM
+#undef STEMS
             break;
         }
         case OP_CONV: {
