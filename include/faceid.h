@@ -60,6 +60,15 @@ int fid_memcpy_h2d(fid_ctx *ctx, void *dst_dev, const void *src, size_t bytes);
 int fid_memcpy_d2h(fid_ctx *ctx, void *dst, const void *src_dev, size_t bytes); /* synchronises */
 int fid_memset(fid_ctx *ctx, void *dst_dev, int value, size_t bytes);
 
+/* ---- pinned host staging + an upload stream: double-buffered H2D for the video front-end (the step before the
+ * path: reference main.py:174-184 reads and uploads one frame at a time).  fid_upload_async copies on a separate
+ * HIP stream, ordered after the compute work enqueued so far (the destination may still be in use);
+ * fid_upload_wait makes the compute stream wait for it -- no host synchronisation in either. */
+int fid_pinned_alloc(fid_ctx *ctx, size_t bytes, void **hptr);
+int fid_pinned_free(fid_ctx *ctx, void *hptr);
+int fid_upload_async(fid_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes);
+int fid_upload_wait(fid_ctx *ctx);
+
 /* ---- timing with HIP events on the context's stream (bench.py roofline leg) ----------------- */
 #define FID_MAX_EVENTS 64
 int fid_event_record(fid_ctx *ctx, int slot);

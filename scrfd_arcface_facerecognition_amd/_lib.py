@@ -33,6 +33,10 @@ SIGNATURES = {
     "fid_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "fid_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "fid_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "fid_pinned_alloc": (C.c_int, [C.c_void_p, C.c_size_t, c_void_pp]),
+    "fid_pinned_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fid_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fid_upload_wait": (C.c_int, [C.c_void_p]),
     "fid_event_record": (C.c_int, [C.c_void_p, C.c_int]),
     "fid_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32_p]),
     "fid_net_create": (C.c_int, [C.c_void_p, c_i32_p, C.c_int, c_i32_p, C.c_int, C.c_void_p, C.c_size_t,

@@ -55,6 +55,8 @@ struct fid_ctx {
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     hipEvent_t events[FID_MAX_EVENTS] = {};
+    hipStream_t copy_stream = nullptr;   // H2D uploads that overlap compute (video front-end)
+    hipEvent_t copy_done = nullptr, compute_done = nullptr;
     // SCRFD post-process state
     int cand_cap = 4096;
     int32_t *status_dev = nullptr;  // [0] max candidates seen, [1] max survivors seen

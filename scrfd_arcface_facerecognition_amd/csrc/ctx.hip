@@ -74,6 +74,9 @@ int fid_ctx_destroy(fid_ctx *ctx) {
     for (int i = 0; i < FID_MAX_EVENTS; i++)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
     if (ctx->status_dev) (void)hipFree(ctx->status_dev);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
+    if (ctx->compute_done) (void)hipEventDestroy(ctx->compute_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FID_OK;
@@ -128,6 +131,46 @@ int fid_memset(fid_ctx *ctx, void *dst, int value, size_t bytes) {
     FID_REQUIRE(ctx && (bytes == 0 || dst), "bad args");
     if (bytes == 0) return FID_OK;
     FID_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return FID_OK;
+}
+
+// ---- pinned host memory + an upload stream: the video front-end's double-buffered H2D (reference main.py:174-184
+// reads one frame at a time; here the next batch is uploaded while the current one is processed) ----
+int fid_pinned_alloc(fid_ctx *ctx, size_t bytes, void **hptr) {
+    FID_REQUIRE(ctx && hptr && bytes > 0, "bad args");
+    FID_HIP(hipSetDevice(ctx->device));
+    FID_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return FID_OK;
+}
+
+int fid_pinned_free(fid_ctx *ctx, void *hptr) {
+    FID_REQUIRE(ctx, "ctx is NULL");
+    if (hptr) FID_HIP(hipHostFree(hptr));
+    return FID_OK;
+}
+
+// enqueue a pinned-host -> device copy on the context's upload stream; it starts only after everything enqueued
+// so far on the compute stream has finished (the destination may still be read by earlier kernels)
+int fid_upload_async(fid_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes) {
+    FID_REQUIRE(ctx && dst_dev && src_pinned && bytes > 0, "bad args");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->copy_stream) {
+        FID_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        FID_HIP(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
+        FID_HIP(hipEventCreateWithFlags(&ctx->compute_done, hipEventDisableTiming));
+    }
+    FID_HIP(hipEventRecord(ctx->compute_done, ctx->stream));
+    FID_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->compute_done, 0));
+    FID_HIP(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    FID_HIP(hipEventRecord(ctx->copy_done, ctx->copy_stream));
+    return FID_OK;
+}
+
+// make the compute stream wait for the uploads enqueued so far (no host synchronisation)
+int fid_upload_wait(fid_ctx *ctx) {
+    FID_REQUIRE(ctx, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->copy_done) FID_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_done, 0));
     return FID_OK;
 }
 

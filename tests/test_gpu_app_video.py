@@ -1,0 +1,65 @@
+"""GPU: the FaceAnalysis-style front end and the double-buffered video runner (f-2) give the same
+faces as the mirrored per-frame API."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_face_analysis_get_matches_per_face_api():
+    from scrfd_arcface_facerecognition_amd.app import FaceAnalysis
+    from scrfd_arcface_facerecognition_amd.pipeline import calibrate_detector_bias
+    from scrfd_arcface_facerecognition_amd.session import HipSession
+    app = FaceAnalysis("synthetic:scrfd_2.5g?seed=1", "synthetic:arcface_mbf?seed=1", max_faces=16)
+    frame = np.random.default_rng(1).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    from oracle import align as oalign
+    P, _ = calibrate_detector_bias(app.ctx, app.det.session.net, app.det.session.params, oalign.letterbox(frame)[0][None],
+                                   target=30, max_batch=1)
+    app.det.session = HipSession(None, ctx=app.ctx, net=app.det.session.net, params=P, max_batch=2)
+    faces = app.get(frame, max_num=5)
+    assert 1 <= len(faces) <= 5
+    det, kpss = app.det.detect(frame, max_num=5)
+    for i, f in enumerate(faces):
+        assert np.array_equal(f.bbox, det[i, :4]) and f.det_score == det[i, 4] and np.array_equal(f.kps, kpss[i])
+        e = app.rec(frame, kpss[i])                                   # the reference's per-face call
+        assert np.allclose(f.embedding, e, rtol=0, atol=2e-2 * np.abs(e).max())   # batch-1 vs batch-n kernels: fp16 noise
+        assert abs(np.linalg.norm(f.normed_embedding) - 1) < 2e-3
+        assert np.abs(f.normed_embedding - f.embedding / np.linalg.norm(f.embedding)).max() < 1e-3
+    assert app.best_face(frame).det_score == max(f.det_score for f in app.get(frame))
+
+
+def test_stream_runner_equals_direct_steps():
+    from scrfd_arcface_facerecognition_amd import archs
+    from scrfd_arcface_facerecognition_amd._lib import Context
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
+    from scrfd_arcface_facerecognition_amd.pipeline import FacePipeline, calibrate_detector_bias
+    from scrfd_arcface_facerecognition_amd.video import StreamRunner
+    from oracle import align as oalign
+    ctx = Context(0)
+    rng = np.random.default_rng(6)
+    B, H, W = 4, 270, 480                                             # 1080p / 4: letterboxed on the device
+    frames = rng.integers(0, 256, (10, H, W, 3), dtype=np.uint8)      # 10 frames = 2 full batches + a ragged tail of 2
+    det_net = archs.scrfd_500m((640, 640))
+    lb = np.stack([oalign.letterbox(f)[0] for f in frames[:4]])
+    det_P, _ = calibrate_detector_bias(ctx, det_net, archs.synth_params(det_net, 3), lb, target=30, max_batch=4)
+    rec_net = archs.mobilefacenet()
+    det = CompiledNet(ctx, det_net, det_P, max_batch=B)
+    rec = CompiledNet(ctx, rec_net, archs.synth_params(rec_net, 3), max_batch=B)
+    gal = Gallery(ctx, rng.standard_normal((20, 512)).astype(np.float32))
+    pipe = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=1)
+    runner = StreamRunner(pipe, gal, (H, W), similarity_thresh=0.02)
+    streamed = list(runner.run(iter(frames)))
+    runner.close()
+    assert len(streamed) == 10
+    for b0 in (0, 4, 8):
+        chunk = np.zeros((B, H, W, 3), np.uint8)
+        n = min(B, 10 - b0)
+        chunk[:n] = frames[b0:b0 + n]
+        pipe.run_step(ctx.to_device(chunk), H, W, gal, 0.02)
+        direct = pipe.results(gal)
+        for i in range(n):
+            a, d = streamed[b0 + i], direct[i]
+            assert len(a) == len(d)
+            for fa, fd in zip(a, d):
+                assert np.array_equal(fa[0], fd[0]) and fa[1] == fd[1] and np.array_equal(fa[2], fd[2]) and fa[3] == fd[3] and fa[4] == fd[4]
+    ctx.close()
