@@ -44,6 +44,8 @@ struct ChunkArgs {
     int res_Cp;
     int tiles_x, tiles_y, n_tiles, n_cblk, n_items, n_chunks;
     unsigned in_bytes, w_bytes;
+    int ablate;   // timing experiments only (FID_CHUNK_ABLATE: 1 = no MFMA/LDS reads, 2 = no DMA, 4 = no epilogue,
+                  // 8 = no epilogue loads, 16 = no output stores, 32 = no flush)
 };
 
 template <int N>
@@ -74,13 +76,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
     // LDS: [weights ring: 2 x W_BYTES][patch ring: PD x PATCH_BYTES]
     char *sWr = smem, *sPr = smem + 2 * W_BYTES;
     // ---- per-lane constants of my DMA blocks (block j = wave + 8*k of the weight / of the patch image) ----
-    int w_t[MAX_W], w_co[MAX_W], w_c[MAX_W];
+    // weights: byte offset of my 16 B inside the cout block's [CB][9][Cin_p] rows; rows past the bank's end fall outside
+    // the buffer descriptor and read as 0 (w_rows == Cout_p is a precondition of this kernel)
+    int w_off[MAX_W];
 #pragma unroll
     for (int k = 0; k < MAX_W; k++) {
         const int row = (wave + 8 * k) * 16 + (lane >> 2);
-        w_c[k] = ((lane & 3) ^ swz64(row)) * 8;
-        w_t[k] = row / CB;
-        w_co[k] = row - w_t[k] * CB;
+        const int t = row / CB, co = row - t * CB;
+        w_off[k] = ((co * 9 + t) * a.Cin_p + ((lane & 3) ^ swz64(row)) * 8) * 2;
     }
     int p_y[MAX_P], p_x[MAX_P], p_c[MAX_P];
 #pragma unroll
@@ -101,16 +104,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
     auto issue_weights = [&](int item, int chunk_k, int slot) {
         int n, ty, tx, cb;
         decode_item(item, n, ty, tx, cb);
-        const int co_base = cb * CB, c0 = chunk_k * CK;
+        const int ubase = (cb * CB * 9 * a.Cin_p + chunk_k * CK) * 2;   // wave-uniform part of the offset
         char *dst = sWr + slot * W_BYTES;
 #pragma unroll
         for (int k = 0; k < MAX_W; k++) {
             const int j = wave + 8 * k;
-            if (j < W_BLKS) {
-                const int co = co_base + w_co[k];
-                const unsigned vo = co < a.w_rows ? (unsigned)(((co * 9 + w_t[k]) * a.Cin_p + c0 + w_c[k]) * 2) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
-            }
+            if (j < W_BLKS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16,
+                                                         (unsigned)(w_off[k] + ubase), 0, 0, 0);
         }
     };
     auto issue_patch = [&](int item, int chunk_k, int slot) {   // exactly MAX_P instructions per wave (vmcnt accounting)
@@ -141,6 +142,72 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
     const int lin0 = (wg * MI) * PW + frow;
     EpiArgs ep{a.bias, a.slope, a.res, a.out, a.Cout_p, a.H, a.W, a.act, a.flags, a.nsig, a.H, a.W, a.res_Cp};
 
+    // ---- epilogue, split in three so that none of its memory latencies is exposed:
+    //   epi_prefetch  before the LAST chunk's MFMAs: bias / slope / residual loads (they return during the matrix work)
+    //   epi_values    after them: bias + residual + activation -> fp16 values kept in registers
+    //   epi_flush     after the NEXT step's barrier: transposed through LDS blocks of the weight slot that step s used
+    //                 (only blocks this wave refills itself, so no second barrier), written as whole 16-byte segments.
+    //                 The stores are then the OLDEST entries of the wave's memory queue and have a whole step to retire.
+    constexpr int OROWB = NI * 32, OCPP = NI * 2, PPI = 64 / OCPP;
+    constexpr int OMASK = (OCPP & (OCPP - 1)) == 0 ? OCPP - 1 : 0;
+    static_assert((64 * OROWB + 1023) / 1024 <= W_BLKS / 8, "staging must fit the wave's own DMA blocks");
+    EpiPix px[MI];
+    int co0[NI];
+    EpiRegs<NI, MI> R;
+    ep_half4 hv[NI][MI];
+    int pend_n = -1, pend_ty = 0, pend_tx = 0, pend_co = 0;      // finished tile waiting for its flush
+    auto epi_prefetch = [&](int item) {
+        int n, ty, tx, cb;
+        decode_item(item, n, ty, tx, cb);
+        // opaque lane id: keeps hipcc from hoisting this block's per-lane address arithmetic out of the step loop (where it
+        // would stay live across the MFMA section and spill)
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int frow = lo & 15, fq = lo >> 4;
+        const int co_w = cb * CB + grp * NI * 16;            // first cout of this wave
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            const int oy = ty * TH + wg * MI + mi, ox = tx * TW + frow;
+            px[mi].valid = oy < a.H && ox < a.W;
+            px[mi].n = n; px[mi].oy = oy; px[mi].ox = ox;
+            px[mi].m = px[mi].valid ? ((long long)n * a.H + oy) * a.W + ox : 0;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) co0[ni] = co_w + ni * 16 + fq * 4;
+        if (!(a.ablate & 8)) epilogue_prefetch<NI, MI>(ep, px, co0, R);
+        pend_ty = ty; pend_tx = tx; pend_co = co_w;
+        return n;
+    };
+    auto stage_addr = [&](char *slot, int off) {              // wave-local staging offset -> LDS address in my own DMA blocks
+        return slot + ((wave + 8 * (off >> 10)) << 10) + (off & 1023);
+    };
+    // (issuing the stores AFTER the step's DMAs, out of registers, measured 5 % slower than this order)
+    auto epi_flush = [&](char *slot) {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int frow = lo & 15, fq = lo >> 4, lane = lo;
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int p = mi * 16 + frow, c = ni * 2 + (fq >> 1);
+                *(ep_half4 *)stage_addr(slot, p * OROWB + ((c ^ (p & OMASK)) << 4) + (fq & 1) * 8) = hv[ni][mi];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s2 = 0; s2 < (64 + PPI - 1) / PPI; s2++) {
+            const int p = s2 * PPI + lane / OCPP, c = lane % OCPP;
+            if (lane < PPI * OCPP && p < 64) {
+                const u32x4 v = *(const u32x4 *)stage_addr(slot, p * OROWB + ((c ^ (p & OMASK)) << 4));
+                const int oy = pend_ty * TH + wg * MI + (p >> 4), ox = pend_tx * TW + (p & 15);
+                if (oy < a.H && ox < a.W && pend_co + c * 8 < a.Cout_p && !(a.ablate & 16))
+                    *(u32x4 *)((char *)a.out + ((((size_t)pend_n * a.H + oy) * a.W + ox) * a.Cout_p + pend_co) * 2 + c * 16) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads are in registers before my DMAs refill the blocks
+        pend_n = -1;
+    };
+
     // prologue: weights of step 0, patches of steps 0 and 1 (issue order matters for the counted waits below:
     // per step the weights of s+1 are issued BEFORE the patch of s+2)
     if (n_steps > 0) {
@@ -156,20 +223,24 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
     int li = 0, ck = 0;                                   // local item index / chunk of the current step
     for (int s = 0; s < n_steps; s++) {
         const int item = blockIdx.x + li * gridDim.x;
-        // outstanding, oldest first: [W(s), P(s) | P(s+1)] at s = 0, else [W(s) | P(s+1)] (P(s) was issued a step
+        // outstanding, oldest first: [W(s), P(s) | P(s+1)] at s = 0, else [stores | W(s) | P(s+1)] (P(s) was issued a step
         // earlier, before W(s)); everything up to W(s) must have landed, only the newest patch may stay in flight
         if (AHEAD == 2 && s + 1 < n_steps) wait_vmcnt_c<MAX_P>();
         else wait_vmcnt_c<0>();
         __syncthreads();                                    // everyone's landed; everyone is done with step s-1's buffers
+        if (pend_n >= 0 && !(a.ablate & 32)) epi_flush(sWr + ((s + 1) & 1) * W_BYTES);   // step s-1's weight slot, before W(s+1) lands in it
+        const bool last_chunk = ck == a.n_chunks - 1;
+        int fin_n = -1;
+        if (last_chunk && !(a.ablate & 4)) fin_n = epi_prefetch(item);
         if (s + 1 < n_steps) {
             int it1, ck1;
             step_item(s + 1, it1, ck1);
-            issue_weights(it1, ck1, (s + 1) & 1);
+            if (!(a.ablate & 2)) issue_weights(it1, ck1, (s + 1) & 1);
         }
         if (s + AHEAD < n_steps) {
             int it2, ck2;
             step_item(s + AHEAD, it2, ck2);
-            issue_patch(it2, ck2, (s + AHEAD) % PD);
+            if (!(a.ablate & 2)) issue_patch(it2, ck2, (s + AHEAD) % PD);
         }
         if (ck == 0) {
 #pragma unroll
@@ -178,81 +249,52 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
                 for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const char *sW = sWr + (s & 1) * W_BYTES, *sP = sPr + (s % PD) * PATCH_BYTES;
-        // software-pipelined over the taps: the fragments of tap t+1 are requested before the MFMAs of tap t issue,
-        // so the LDS latency hides behind matrix work instead of stalling every group
-        half8 wf[2][NI], pf[2][MI];
-        auto load_tap = [&](int t, int set) {
-            const int dy = t / 3, dx = t % 3;
+        // LDS-read-lean tap order.  The naive order (per tap: NI weight + 4 pixel fragments for 4*NI MFMAs) reads 63 KB per
+        // wave and chunk -- 504 KB per CU against 128 B/clk of LDS bandwidth is 1.64 us, more than the 1.44 us the MFMAs
+        // take.  A pixel fragment (patch row r, column shift dx) serves every output row mi = r - dy, so the loop walks
+        // dx, then the 6 patch rows of this wave: 18 pixel + 27 weight fragment reads per chunk (45 KB, -29 %).
+        // Weights of the column's three taps sit in registers (9 fragments); set dy is reloaded for the next column as
+        // soon as its last use (row 3 + dy) has issued.  Pixel fragments are requested two row-steps ahead.
+        if (!(a.ablate & 1)) {
+            int plin = lin0, wlane = ((grp * NI) * 16 + frow) * 64 + ((fq ^ swz64(frow)) << 4);
+            asm volatile("" : "+v"(plin), "+v"(wlane));   // opaque: recompute the fragment addresses per step instead of
+                                                            // keeping 18 + 27 of them live across the whole loop
+            half8 wq[3][NI], pq[3];
+            auto load_w = [&](int dy, int dx) {            // weight rows (t*CB + ni*16 + frow): t*CB and ni*16 are multiples of 16,
+#pragma unroll                                             // so the swizzle term only depends on frow
+                for (int ni = 0; ni < NI; ni++) wq[dy][ni] = *(const half8 *)(sW + wlane + ((dy * 3 + dx) * CB + ni * 16) * 64);
+            };
+            auto load_p = [&](int q, int set) {            // q = dx*6 + r
+                const int lin = plin + (q % 6) * PW + q / 6;
+                pq[set] = *(const half8 *)(sP + lin * 64 + ((fq ^ swz64(lin)) << 4));
+            };
+            load_w(0, 0); load_p(0, 0); load_w(1, 0); load_p(1, 1); load_w(2, 0);
 #pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-                const int row = t * CB + (grp * NI + ni) * 16 + frow;
-                wf[set][ni] = *(const half8 *)(sW + row * 64 + ((fq ^ swz64(row)) << 4));
-            }
+            for (int q = 0; q < 18; q++) {
+                const int dx = q / 6, r = q % 6;
+                if (q + 2 < 18) load_p(q + 2, (q + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);       // keep the requests ahead of this row's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
-                const int lin = lin0 + (mi + dy) * PW + dx;
-                pf[set][mi] = *(const half8 *)(sP + lin * 64 + ((fq ^ swz64(lin)) << 4));
-            }
-        };
-        load_tap(0, 0);
+                for (int dy = 0; dy < 3; dy++) {
+                    const int mi = r - dy;
+                    if (mi < 0 || mi >= MI) continue;
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-            if (t + 1 < 9) load_tap(t + 1, (t + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this tap's MFMAs (hipcc sinks it otherwise)
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t & 1][ni], pf[t & 1][mi], acc[ni][mi], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ck == a.n_chunks - 1) {
-            // ---- item finished: epilogue, transposed through this (now idle) buffer into whole-row stores ----
-            const int tile = item / a.n_cblk, cb = item - tile * a.n_cblk;
-            const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
-            const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-            const int co_w = cb * CB + grp * NI * 16;       // first cout of this wave
-            EpiPix px[MI];
-            int co0[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
-                const int oy = ty * TH + wg * MI + mi, ox = tx * TW + frow;
-                px[mi].valid = oy < a.H && ox < a.W;
-                px[mi].n = n; px[mi].oy = oy; px[mi].ox = ox;
-                px[mi].m = px[mi].valid ? ((long long)n * a.H + oy) * a.W + ox : 0;
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) co0[ni] = co_w + ni * 16 + fq * 4;
-            if (a.flags & CF_OUT_F32) {
-                epilogue_tile<NI, MI>(ep, acc, px, co0);
-            } else {
-                constexpr int OROWB = NI * 32, OCPP = NI * 2, PPI = 64 / OCPP;
-                constexpr int OMASK = (OCPP & (OCPP - 1)) == 0 ? OCPP - 1 : 0;
-                ep_half4 hv[NI][MI];
-                epilogue_values<NI, MI>(ep, acc, px, co0, hv);
-                __syncthreads();                              // all waves are done reading this buffer's operands
-                char *sS = (char *)sW + wave * (64 * OROWB);     // this step's weight slot is idle now
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ni++) {
-                        const int p = mi * 16 + frow, c = ni * 2 + (fq >> 1);
-                        *(ep_half4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4) + (fq & 1) * 8) = hv[ni][mi];
-                    }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int s2 = 0; s2 < (64 + PPI - 1) / PPI; s2++) {
-                    const int p = s2 * PPI + lane / OCPP, c = lane % OCPP;
-                    if (lane < PPI * OCPP && p < 64) {
-                        const u32x4 v = *(const u32x4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4));
-                        const int oy = ty * TH + wg * MI + (p >> 4), ox = tx * TW + (p & 15);
-                        if (oy < a.H && ox < a.W && co_w + c * 8 < a.Cout_p)
-                            *(u32x4 *)((char *)a.out + ((((size_t)n * a.H + oy) * a.W + ox) * a.Cout_p + co_w) * 2 + c * 16) = v;
-                    }
+                    for (int ni = 0; ni < NI; ni++)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[dy][ni], pq[q % 3], acc[ni][mi], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (dx < 2 && r >= 3) load_w(r - 3, dx + 1);   // taps (r-3, dx) are done: fetch that set for the next column
             }
+        }
+        if (fin_n >= 0) {
+            epilogue_values_fast<NI, MI>(ep, acc, px, co0, R, hv);
+            pend_n = fin_n;
         }
         if (++ck == a.n_chunks) { ck = 0; li++; }
+    }
+    if (pend_n >= 0) {
+        __syncthreads();                                    // all waves are done reading the last step's weight slot
+        epi_flush(sWr + ((n_steps - 1) & 1) * W_BYTES);
     }
 }
 
@@ -276,11 +318,12 @@ int launch_chunked(fid_ctx *ctx, const ChunkArgs &a) {
 
 bool conv_chunked_applicable(const ConvArgs &a) {
     return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Cin_p % 32 == 0 && a.Cin_p >= 64 && a.Cout_p >= 64 &&
-           a.w_rows == a.Cout_p && a.H == a.Ho && a.W == a.Wo && a.H >= 12 && a.W >= 12 && !(a.flags & (CF_RES_UP2 | CF_ARGMAX)) &&
+           a.w_rows == a.Cout_p && a.H == a.Ho && a.W == a.Wo && a.H >= 12 && a.W >= 12 &&
+           !(a.flags & (CF_RES_UP2 | CF_ARGMAX | CF_OUT_F32)) && a.nsig == 0 &&
            (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo));
 }
 
-// cb: output channels per workgroup (64 or 96)
+// cb: output channels per work item (64 or 96)
 int conv_chunked_launch(fid_ctx *ctx, const ConvArgs &c, int cb) {
     ChunkArgs a{};
     a.in = c.in; a.w = c.w; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
@@ -291,7 +334,9 @@ int conv_chunked_launch(fid_ctx *ctx, const ConvArgs &c, int cb) {
     a.n_cblk = cdiv(c.Cout_p, cb);
     a.n_items = a.n_tiles * a.n_cblk;
     a.n_chunks = c.Cin_p / CK;
-    a.in_bytes = c.in_bytes; a.w_bytes = c.w_bytes;
+    a.in_bytes = c.in_bytes;
+    a.w_bytes = std::min<size_t>(c.w_bytes, (size_t)c.w_rows * 9 * c.Cin_p * 2);   // rows past the bank read as 0
+    if (const char *e = getenv("FID_CHUNK_ABLATE")) a.ablate = atoi(e);
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
     if (cb == 64) return launch_chunked<2>(ctx, a);
     if (cb == 96) return launch_chunked<3>(ctx, a);
