@@ -106,15 +106,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_direct(const DirectArgs a) {
     }
 
     // ---- per-lane constants of the patch fetch: which patch pixel / chunk each of my DMA lanes fills ----
-    int p_py[MAX_PI], p_px[MAX_PI], p_ch[MAX_PI];
+    // packed py | px << 8 | channel offset << 16 (one register per block; py = 255 marks a padding row)
+    int p_pk[MAX_PI];
 #pragma unroll
     for (int k = 0; k < MAX_PI; k++) {
         const int j = dma_block(k);
         const int lin = j * PXI + lane / CPP;
-        p_py[k] = lin / PW;
-        p_px[k] = lin - p_py[k] * PW;
-        p_ch[k] = ((lane % CPP) ^ swz<ROWB>(lin)) * 8;
-        if (j >= N_PINSTR || lin >= NPIX) p_py[k] = -100000;  // never inside an image
+        int py = lin / PW;
+        const int px = lin - py * PW;
+        const int ch = ((lane % CPP) ^ swz<ROWB>(lin)) * 8;
+        if (j >= N_PINSTR || lin >= NPIX) py = 255;   // never inside an image
+        p_pk[k] = py | (px << 8) | (ch << 16);
     }
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     auto fetch_patch = [&](int tile) {
@@ -126,9 +128,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_direct(const DirectArgs a) {
         for (int k = 0; k < MAX_PI; k++) {
             const int j = dma_block(k);
             if (j < N_PINSTR) {
-                const int iy = y0 + p_py[k], ix = x0 + p_px[k];
-                const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * CIN_P + p_ch[k]) * 2) : OOB;
+                int pk = p_pk[k];
+                asm volatile("" : "+v"(pk));                     // opaque: unpack here, do not hoist three registers per block
+                const int py = pk & 255, iy = y0 + py, ix = x0 + ((pk >> 8) & 255);
+                const bool in = py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * CIN_P + (pk >> 16)) * 2) : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(sP + j * 1024), 16, vo, 0, 0, 0);
             }
         }
@@ -153,24 +157,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_direct(const DirectArgs a) {
         const int next = tile_of(i + 1);
         const bool have_next = (i + 1 < my_pairs) && next < a.n_tiles;
 
-        EpiPix px[MI];
-        int co0[NI];
-        {
-            const int tl = have ? tile : 0;
-            const int n = tl / tiles_per_img;
-            const int r = tl - n * tiles_per_img;
-            const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
-            const int ox = tx * TW + frow;
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
-                const int oy = ty * TH + wg * MI + mi;
-                px[mi].valid = have && oy < a.H && ox < a.W;
-                px[mi].n = n; px[mi].oy = oy; px[mi].ox = ox;
-                px[mi].m = px[mi].valid ? ((long long)n * a.H + oy) * a.W + ox : 0;
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) co0[ni] = ni * 16 + fq * 4;
-        }
         f32x4 acc[NI][MI];
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
@@ -178,28 +164,42 @@ __global__ void __launch_bounds__(512, 2) conv3x3_direct(const DirectArgs a) {
             for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // ---- compute half-period: 9 taps x Cin_p/32 MFMA steps out of LDS, no barrier inside ----
-        if (have && !(a.flags & (1 << 28)))
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const int dy = t / 3, dx = t % 3;
+        // Order: K chunk, column shift dx, then the 6 patch rows of this wave.  A pixel fragment (row r, shift dx) feeds
+        // every output row mi = r - dy, so a chunk needs 18 pixel + 9*NI weight fragment reads instead of 36 + 9*NI
+        // (the naive per-tap order made the LDS reads as long as the MFMAs).  The column's three taps keep their
+        // weights in registers; set dy is refetched for the next column right after its last use (row 3 + dy).
+        if (have && !(a.flags & (1 << 28))) {
+            int plin = lin0, wrow = frow;
+            asm volatile("" : "+v"(plin), "+v"(wrow));    // opaque: fragment addresses are recomputed per tile, not kept live
+            half8 wq[3][NI], pq[3];
 #pragma unroll
             for (int kk = 0; kk < KK; kk++) {
-                half8 wf[NI], pf[MI];
+                auto load_w = [&](int dy, int dx) {        // rows t*COUT_P + ni*16 + frow: the swizzle term only depends on frow
 #pragma unroll
-                for (int ni = 0; ni < NI; ni++) {
-                    const int row = t * COUT_P + ni * 16 + frow;
-                    wf[ni] = *(const half8 *)(sW + row * ROWB + (((kk * 4 + fq) ^ swz<ROWB>(row)) << 4));
+                    for (int ni = 0; ni < NI; ni++)
+                        wq[dy][ni] = *(const half8 *)(sW + (wrow + (dy * 3 + dx) * COUT_P + ni * 16) * ROWB + (((kk * 4 + fq) ^ swz<ROWB>(wrow)) << 4));
+                };
+                auto load_p = [&](int q, int set) {        // q = dx*6 + r
+                    const int lin = plin + (q % 6) * PW + q / 6;
+                    pq[set] = *(const half8 *)(sP + lin * ROWB + (((kk * 4 + fq) ^ swz<ROWB>(lin)) << 4));
+                };
+                load_w(0, 0); load_p(0, 0); load_w(1, 0); load_p(1, 1); load_w(2, 0);
+#pragma unroll
+                for (int q = 0; q < 18; q++) {
+                    const int dx = q / 6, r = q % 6;
+                    if (q + 2 < 18) load_p(q + 2, (q + 2) % 3);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of this row's MFMAs
+#pragma unroll
+                    for (int dy = 0; dy < 3; dy++) {
+                        const int mi = r - dy;
+                        if (mi < 0 || mi >= MI) continue;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ni++)
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[dy][ni], pq[q % 3], acc[ni][mi], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dx < 2 && r >= 3) load_w(r - 3, dx + 1);
                 }
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++) {
-                    const int lin = lin0 + (mi + dy) * PW + dx;
-                    pf[mi] = *(const half8 *)(sP + lin * ROWB + (((kk * 4 + fq) ^ swz<ROWB>(lin)) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-                    for (int mi = 0; mi < MI; mi++)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[mi], acc[ni][mi], 0, 0, 0);
             }
         }
         __syncthreads();   // my group is done reading its patch; the other group starts computing
@@ -207,7 +207,28 @@ __global__ void __launch_bounds__(512, 2) conv3x3_direct(const DirectArgs a) {
         // ---- memory half-period: store my finished tile, fetch my next patch (latency hides behind the other group) ----
         if (SCR_DEDICATED && have_next) fetch_patch(next);
         if (have && !(a.flags & (1 << 29))) {
-            if (a.flags & CF_OUT_F32) {
+            int lo = lane;                                       // opaque lane id: the pixel / staging / store address arithmetic of
+            asm volatile("" : "+v"(lo));                         // the epilogue is done here, per tile, instead of living across the
+            const int lane = lo, frow = lo & 15, fq = lo >> 4;   // MFMA section (where it spilled)
+            EpiPix px[MI];
+            int co0[NI];
+            {
+                const int tl = have ? tile : 0;
+                const int n = tl / tiles_per_img;
+                const int r = tl - n * tiles_per_img;
+                const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+                const int ox = tx * TW + frow;
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++) {
+                    const int oy = ty * TH + wg * MI + mi;
+                    px[mi].valid = have && oy < a.H && ox < a.W;
+                    px[mi].n = n; px[mi].oy = oy; px[mi].ox = ox;
+                    px[mi].m = px[mi].valid ? ((long long)n * a.H + oy) * a.W + ox : 0;
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) co0[ni] = ni * 16 + fq * 4;
+            }
+            if (COUT_P == 32 && (a.flags & CF_OUT_F32)) {     // fp32 outputs (detector head maps) only exist 32 wide
                 epilogue_tile<NI, MI>(ep, acc, px, co0);
             } else {
                 ep_half4 hv[NI][MI];
@@ -269,7 +290,8 @@ bool conv_direct_applicable(const ConvArgs &a) {
     if (getenv("FID_NO_DIRECT")) return false;
     return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Cin_p == 32 || a.Cin_p == 64) &&
            (a.Cout_p == 32 || a.Cout_p == 64) && a.w_rows == a.Cout_p && a.H == a.Ho && a.W == a.Wo && a.H >= 16 && a.W >= 16 &&
-           !(a.flags & (CF_RES_UP2 | CF_ARGMAX)) && (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo));
+           !(a.flags & (CF_RES_UP2 | CF_ARGMAX)) && (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo)) &&
+           (a.Cout_p == 32 || (!(a.flags & CF_OUT_F32) && a.nsig == 0));
 }
 
 int conv_direct_launch(fid_ctx *ctx, const ConvArgs &c) {

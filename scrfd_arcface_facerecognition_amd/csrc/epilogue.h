@@ -125,53 +125,11 @@ __device__ __forceinline__ void epilogue_finish(const EpiArgs &e, ep_f32x4 (&acc
     }
 }
 
-// bias + residual + activation in the accumulator layout, result as fp16 (no store): for kernels that
-// transpose the tile through LDS and write whole 128-byte lines.  R was filled by epilogue_prefetch.
-template <int NI, int MI>
-__device__ __forceinline__ void epilogue_values_pre(const EpiArgs &e, ep_f32x4 (&acc)[NI][MI], const EpiPix (&px)[MI], const int (&co0)[NI],
-                                                    const EpiRegs<NI, MI> &R, ep_half4 (&h)[NI][MI]) {
-    const bool has_res = e.res != nullptr;
-    const bool border = (e.flags & CF_BORDER) != 0;
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++) {
-        ep_f32x4 bm[NI];
-        if (border) {
-            const int cls = (px[mi].oy == 0 ? 0 : (px[mi].oy == e.Ho - 1 ? 2 : 1)) * 3 + (px[mi].ox == 0 ? 0 : (px[mi].ox == e.Wo - 1 ? 2 : 1));
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) bm[ni] = *(const ep_f32x4 *)(e.bias + (size_t)cls * e.Cout_p + (co0[ni] < e.Cout_p ? co0[ni] : 0));
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++) {
-            ep_f32x4 v = acc[ni][mi] + (border ? bm[ni] : R.bb[ni]);
-            if (has_res) {
-                v[0] += (float)R.rr[ni][mi][0]; v[1] += (float)R.rr[ni][mi][1];
-                v[2] += (float)R.rr[ni][mi][2]; v[3] += (float)R.rr[ni][mi][3];
-            }
-            if (e.act == ACT_RELU) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.f);
-            } else if (e.act == ACT_PRELU) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) v[i] = v[i] > 0.f ? v[i] : v[i] * R.sl[ni][i];
-            }
-            h[ni][mi][0] = (_Float16)v[0]; h[ni][mi][1] = (_Float16)v[1];
-            h[ni][mi][2] = (_Float16)v[2]; h[ni][mi][3] = (_Float16)v[3];
-        }
-    }
-}
-
-template <int NI, int MI>
-__device__ __forceinline__ void epilogue_values(const EpiArgs &e, ep_f32x4 (&acc)[NI][MI], const EpiPix (&px)[MI], const int (&co0)[NI],
-                                                ep_half4 (&h)[NI][MI]) {
-    EpiRegs<NI, MI> R;
-    epilogue_prefetch<NI, MI>(e, px, co0, R);
-    epilogue_values_pre<NI, MI>(e, acc, px, co0, R, h);
-}
-
-// ---- straight-line variants of the fp16 value path ----------------------------------------------------------
-// epilogue_values_pre above decides activation / residual per VALUE on runtime flags: hipcc turns that into scalar
-// branches between every few vector instructions (measured on the chunked conv: 2.5 us per 256x96 tile, more
-// than a third of its matrix time).  Here the flags select ONE of six fully unrolled bodies per tile.  ReLU is
+// ---- fp16 value path: bias + residual + activation in the accumulator layout, result as fp16 (no store), for
+// kernels that transpose the tile through LDS and write whole 16-byte cout segments.
+// Deciding activation / residual per VALUE on runtime flags makes hipcc emit scalar branches between every few
+// vector instructions (measured on the chunked conv: 2.5 us per 256x96 tile, more than a third of its matrix
+// time).  Here the flags select ONE of six fully unrolled bodies per tile.  ReLU is
 // applied after the fp16 rounding with packed max (exactly the same result: rounding is monotone and keeps the
 // sign), bias adds are 2-wide packed fp32.
 template <int ACT, bool RES, int NI, int MI>
@@ -218,6 +176,15 @@ __device__ __forceinline__ void epilogue_values_fast(const EpiArgs &e, ep_f32x4 
         if (res) epilogue_values_body<ACT_NONE, true, NI, MI>(e, acc, px, co0, R, h);
         else epilogue_values_body<ACT_NONE, false, NI, MI>(e, acc, px, co0, R, h);
     }
+}
+
+// loads + values in one call (kernels that do not prefetch)
+template <int NI, int MI>
+__device__ __forceinline__ void epilogue_values(const EpiArgs &e, ep_f32x4 (&acc)[NI][MI], const EpiPix (&px)[MI], const int (&co0)[NI],
+                                                ep_half4 (&h)[NI][MI]) {
+    EpiRegs<NI, MI> R;
+    epilogue_prefetch<NI, MI>(e, px, co0, R);
+    epilogue_values_fast<NI, MI>(e, acc, px, co0, R, h);
 }
 
 template <int NI, int MI>
