@@ -41,6 +41,27 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Division of a non-negative int (< 2^31) by a launch-time constant as multiply-high + shift: the kernels decode
+// (item -> image, tile row, tile column, cout block) several times per step, and a runtime integer division costs
+// ~40 instructions each.  q = x / d  ==  d == 1 ? x : umulhi(x, mul) >> shr.
+struct FastDiv {
+    unsigned mul, shr, d;
+};
+inline FastDiv fastdiv_make(int d) {
+    FastDiv f{0u, 0u, (unsigned)d};
+    if (d > 1) {
+        unsigned lg = 0;
+        while ((1ull << lg) < (unsigned long long)d) lg++;      // ceil(log2(d))
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)(((1ull << p) + (unsigned)d - 1) / (unsigned)d);
+        f.shr = p - 32;
+    }
+    return f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int fastdiv(int x, const FastDiv &f) { return f.d == 1 ? x : (int)(__umulhi((unsigned)x, f.mul) >> f.shr); }
+#endif
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace fid

@@ -610,6 +610,15 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
         d.bn = 64; out.push_back(d);
         if (a.Cout_p % 96 == 0) { d.bn = 96; out.push_back(d); }
     }
+    if (conv_pp_applicable(a)) {
+        ConvPlan d{};
+        d.gen = 4; d.ksplit = 1; d.bm = 512; d.bk = 32;
+        for (int cb : {32, 48, 64}) {
+            if (cb > 32 && cdiv(a.Cout_p, cb) * cb > cdiv(a.Cout_p, 32) * 32) continue;   // would pad more couts than cb = 32
+            d.bn = cb;
+            out.push_back(d);
+        }
+    }
     const int bk = (a.Cin_p % 64 == 0) ? 64 : 32;
     const int ksteps = a.kh * a.kw * (a.Cin_p / bk);
     auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
@@ -646,6 +655,7 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 0) return conv_direct_launch(ctx, a);
     if (plan.gen == 3) return conv_chunked_launch(ctx, a, plan.bn);
+    if (plan.gen == 4) return conv_pp_launch(ctx, a, plan.bn);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);
     FID_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 4 == 0, "conv: channel padding (Cin_p=%d Cout_p=%d)", a.Cin_p, a.Cout_p);
