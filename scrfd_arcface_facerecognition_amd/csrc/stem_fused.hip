@@ -145,6 +145,18 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
         koff[j] = k < 27 ? (dy * RI + dx) * 3 + c : -1;
     }
 
+    // biases in registers for the workgroup's lifetime: read inside the tile loop they are a global load + full wait per
+    // (subtile, cout group) -- up to 12 serial round trips per stage (measured: 477 -> 412 us at 32 frames).
+    // (Software-pipelining the S2/S3 tap loops like conv_chunked.hip was measured 8 % SLOWER here, same box A/B.)
+    f32x4 bias0[2], bias1[2], bias2[NI2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ni++) {
+        bias0[ni] = *(const f32x4 *)(a.b0 + ni * 16 + fq * 4);
+        bias1[ni] = *(const f32x4 *)(a.b1 + ni * 16 + fq * 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI2; ni++) bias2[ni] = *(const f32x4 *)(a.b2 + ni * 16 + fq * 4);
+
     int tile = blockIdx.x;
     if (tile < a.n_tiles) prefetch(tile);
     __syncthreads();
@@ -177,8 +189,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
                 const half8 wf = *(const half8 *)(sW0 + (ni * 16 + frow) * 64 + fq * 16);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, pf, acc, 0, 0, 0);
-                const int co0 = ni * 16 + fq * 4;
-                const f32x4 b = *(const f32x4 *)(a.b0 + co0);
+                const f32x4 b = bias0[ni];
                 half4 h;
 #pragma unroll
                 for (int i = 0; i < 4; i++) h[i] = inside ? (_Float16)fmaxf(acc[i] + b[i], 0.f) : (_Float16)0.f;
@@ -234,8 +245,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
                 if (!have[mi] || qd[mi] >= N1) continue;
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++) {
-                    const int co0 = ni * 16 + fq * 4;
-                    const f32x4 b = *(const f32x4 *)(a.b1 + co0);
+                    const f32x4 b = bias1[ni];
                     half4 h;
 #pragma unroll
                     for (int i = 0; i < 4; i++) h[i] = inside[mi] ? (_Float16)fmaxf(acc[ni][mi][i] + b[i], 0.f) : (_Float16)0.f;
@@ -294,8 +304,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
                 if (!have[mi] || qd[mi] >= N2) continue;
 #pragma unroll
                 for (int ni = 0; ni < NI2; ni++) {
-                    const int co0 = ni * 16 + fq * 4;
-                    const f32x4 b = *(const f32x4 *)(a.b2 + co0);
+                    const f32x4 b = bias2[ni];
                     half4 h;
 #pragma unroll
                     for (int i = 0; i < 4; i++) h[i] = inside[mi] ? (_Float16)fmaxf(acc[ni][mi][i] + b[i], 0.f) : (_Float16)0.f;
