@@ -35,7 +35,7 @@ struct ConvArgs {
 struct ConvPlan {
     int bm, bn, bk, ksplit;
     int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp (bn = couts per work item)
-    int ns;    // ring slots (gen 2)
+    int ns;    // ring slots (gen 2); 5 = 4 slots + fragment prefetch across K-steps
     size_t partial_bytes;
 };
 ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split);

@@ -358,7 +358,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int NS, int WM, int WN>
+template <int BM, int BN, int BK, int NS, int WM, int WN, bool PF = false>
 __global__ void __launch_bounds__(256, (NS * (BM + (BN + 256 / (BK / 8) - 1) / (256 / (BK / 8)) * (256 / (BK / 8))) * BK * 2 <= 80 * 1024) ? 2 : 1)
     conv_mfma_dma_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -459,6 +459,60 @@ __global__ void __launch_bounds__(256, (NS * (BM + (BN + 256 / (BK / 8) - 1) / (
 
     const int frow = lane & 15, fq = lane >> 4;
     constexpr int KK = BK / 32;
+    if constexpr (PF) {
+        // Fragment-prefetch variant (the autotuner's "ns = 5": 4 slots).  With 64x64 tiles a K-step is only 8 MFMAs per
+        // wave (128 cycles) while the barrier plus the first ds_read latency of the step cost ~300: the kernel ran at a
+        // quarter of the MFMA rate even with the DMA switched off.  Here the barrier of step k also covers stage k+1, so
+        // the fragments of (k+1, kk = 0) are requested during step k's last MFMA group and a step starts multiplying at
+        // once.  Price: one K-step less of DMA look-ahead (NS-2 stages in flight instead of NS-1).
+        static_assert(NS == 4, "fragment prefetch needs 4 ring slots");
+        half8 wf[2][NI], pf[2][MI];
+        auto load_frags = [&](int kstep, int kk, int set) {
+            const char *cA = smem + (kstep % NS) * STAGE, *cB = cA + BM * ROWB;
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int row = wm * TM + mi * 16 + frow;
+                pf[set][mi] = *(const half8 *)(cA + row * ROWB + (((kk * 4 + fq) ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int row = wn * TN + ni * 16 + frow;
+                wf[set][ni] = *(const half8 *)(cB + row * ROWB + (((kk * 4 + fq) ^ swz<BK>(row)) << 4));
+            }
+        };
+        // stage 0 landed (stages 1, 2 may be in flight)
+        if (nk >= 3) wait_vmcnt<2 * L>();
+        else if (nk == 2) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0, 0);
+        for (int k = 0; k < nk; k++) {
+            // stage k+1 must have landed for everyone: only stage k+2 may stay in flight
+            if (k + 2 < nk) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();       // also: everyone is done reading slot (k-1)%NS
+            const bool more = k + NS - 1 < nk;
+            if (more) {
+                stage_begin();
+#pragma unroll
+                for (int j = 0; j < L; j++) stage_piece((k + NS - 1) % NS, j);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                const int cur = kk & 1;
+                if (kk + 1 < KK) load_frags(k, kk + 1, cur ^ 1);
+                else if (k + 1 < nk) load_frags(k + 1, 0, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cur][ni], pf[cur][mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) stage_end();
+        }
+    } else
     for (int k = 0; k < nk; k++) {
         // stage k must have landed: allow only the younger stages (at most NS-2 of them) to be outstanding
         const int younger = min(NS - 2, nk - 1 - k);
@@ -525,17 +579,17 @@ int launch_cfg(fid_ctx *ctx, const ConvArgs &a) {
     return FID_OK;
 }
 
-template <int BM, int BN, int BK, int NS, int WM, int WN>
+template <int BM, int BN, int BK, int NS, int WM, int WN, bool PF = false>
 int launch_dma(fid_ctx *ctx, const ConvArgs &a) {
     constexpr int RPP = 4 * (64 / (BK / 8));
     constexpr size_t lds = (size_t)NS * (BM + (BN + RPP - 1) / RPP * RPP) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FID_HIP(hipFuncSetAttribute((const void *)conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, a.ksplit);
-    hipLaunchKernelGGL((conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN>), grid, dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN, PF>), grid, dim3(256), lds, ctx->stream, a);
     return FID_OK;
 }
 
@@ -642,6 +696,7 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
             add(gen, 128, 128, 4); add(gen, 128, 64, 4); add(gen, 64, 64, 4);
         }
         add(2, 128, 128, 3); add(2, 128, 64, 3); add(2, 64, 64, 3);
+        add(2, 128, 128, 5); add(2, 128, 64, 5); add(2, 64, 64, 5);   // ns = 5: 4 slots + fragment prefetch across K-steps
     } else {
         for (int gen = 1; gen <= 2; gen++) {
             add(gen, 128, 128, 4); add(gen, 128, 96, 4); add(gen, 128, 64, 4); add(gen, 128, 32, 4);
@@ -675,6 +730,9 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
         switch (key) {
             case 128128644: rc = launch_dma<128, 128, 64, 4, 2, 2>(ctx, a); break;
             case 128128643: rc = launch_dma<128, 128, 64, 3, 2, 2>(ctx, a); break;
+            case 128128645: rc = launch_dma<128, 128, 64, 4, 2, 2, true>(ctx, a); break;
+            case 128064645: rc = launch_dma<128, 64, 64, 4, 2, 2, true>(ctx, a); break;
+            case 64064645: rc = launch_dma<64, 64, 64, 4, 2, 2, true>(ctx, a); break;
             case 128064644: rc = launch_dma<128, 64, 64, 4, 2, 2>(ctx, a); break;
             case 128064643: rc = launch_dma<128, 64, 64, 3, 2, 2>(ctx, a); break;
             case 64064644: rc = launch_dma<64, 64, 64, 4, 2, 2>(ctx, a); break;

@@ -30,11 +30,15 @@ def stack(hw, chans, res=True):
     return net
 
 
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 25])     # 25 = generation 2 with ns = 5 (fragment prefetch across K-steps)
 @pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2)])
 def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
-    monkeypatch.setenv("FID_FORCE_GEN", str(gen))
+    if gen == 25:
+        monkeypatch.setenv("FID_FORCE_GEN", "2")
+        monkeypatch.setenv("FID_FORCE_NS", "5")
+    else:
+        monkeypatch.setenv("FID_FORCE_GEN", str(gen))
     net = stack(hw, chans)
     P = archs.synth_params(net, seed=9)
     images = np.random.default_rng(3).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
