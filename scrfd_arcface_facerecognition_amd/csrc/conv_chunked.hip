@@ -43,6 +43,7 @@ struct ChunkArgs {
     int act, flags, nsig;
     int res_Cp;
     int tiles_x, tiles_y, n_tiles, n_cblk, n_items, n_chunks;
+    FastDiv d_cblk, d_tpi, d_tx;             // divisions by n_cblk, tiles per image, tiles_x
     unsigned in_bytes, w_bytes;
     int ablate;   // timing experiments only (FID_CHUNK_ABLATE: 1 = no MFMA/LDS reads, 2 = no DMA, 4 = no epilogue,
                   // 8 = no epilogue loads, 16 = no output stores, 32 = no flush)
@@ -95,16 +96,41 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
         if (row >= NPIX) p_y[k] = -100000;                  // padding rows of the patch image: always read as 0
     }
     auto decode_item = [&](int item, int &n, int &ty, int &tx, int &cb) {
-        const int tile = item / a.n_cblk;
+        const int tile = fastdiv(item, a.d_cblk);
         cb = item - tile * a.n_cblk;
-        n = tile / tiles_per_img;
+        n = fastdiv(tile, a.d_tpi);
         const int r = tile - n * tiles_per_img;
-        ty = r / a.tiles_x; tx = r - ty * a.tiles_x;
+        ty = fastdiv(r, a.d_tx); tx = r - ty * a.tiles_x;
     };
-    auto issue_weights = [&](int item, int chunk_k, int slot) {
+    // A prefetch stream walks the (item, chunk) sequence of this workgroup one chunk per step.  Its cursor keeps the
+    // DECODED item and only re-decodes when the item changes: decoding both streams from scratch every step (six runtime
+    // integer divisions) was stamped at ~1100 cycles per step, a third of the step's MFMA time, on all SIMDs at once.
+    struct Cursor {
+        int item, ck;      // work item / chunk the NEXT issue of this stream fetches
+        int w_base;        // weights: byte offset of the item's cout block (chunk 0)
+        int n, y0, x0;     // patch: image, top-left input pixel of the haloed patch
+    };
+    auto cursor_decode = [&](Cursor &c) {
         int n, ty, tx, cb;
-        decode_item(item, n, ty, tx, cb);
-        const int ubase = (cb * CB * 9 * a.Cin_p + chunk_k * CK) * 2;   // wave-uniform part of the offset
+        decode_item(c.item, n, ty, tx, cb);
+        c.w_base = cb * CB * 9 * a.Cin_p * 2;
+        c.n = n; c.y0 = ty * TH - 1; c.x0 = tx * TW - 1;
+    };
+    auto cursor_init = [&](Cursor &c, int step) {          // position on step `step` of this workgroup (prologue only)
+        const int li = step / a.n_chunks;
+        c.ck = step - li * a.n_chunks;
+        c.item = blockIdx.x + li * gridDim.x;
+        cursor_decode(c);
+    };
+    auto cursor_next = [&](Cursor &c) {
+        if (++c.ck == a.n_chunks) {
+            c.ck = 0;
+            c.item += gridDim.x;
+            cursor_decode(c);
+        }
+    };
+    auto issue_weights = [&](const Cursor &c, int slot) {
+        const int ubase = c.w_base + c.ck * CK * 2;          // wave-uniform part of the offset
         char *dst = sWr + slot * W_BYTES;
 #pragma unroll
         for (int k = 0; k < MAX_W; k++) {
@@ -114,25 +140,17 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
                                                          (unsigned)(w_off[k] + ubase), 0, 0, 0);
         }
     };
-    auto issue_patch = [&](int item, int chunk_k, int slot) {   // exactly MAX_P instructions per wave (vmcnt accounting)
-        int n, ty, tx, cb;
-        decode_item(item, n, ty, tx, cb);
-        const int y0 = ty * TH - 1, x0 = tx * TW - 1, c0 = chunk_k * CK;
+    auto issue_patch = [&](const Cursor &c, int slot) {   // exactly MAX_P instructions per wave (vmcnt accounting)
+        const int c0 = c.ck * CK;
         char *dst = sPr + slot * PATCH_BYTES;
 #pragma unroll
         for (int k = 0; k < MAX_P; k++) {
             const int j = wave + 8 * k;
-            const int iy = y0 + p_y[k], ix = x0 + p_x[k];
+            const int iy = c.y0 + p_y[k], ix = c.x0 + p_x[k];
             const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + p_c[k]) * 2) : OOB;
+            const unsigned vo = in ? (unsigned)((((c.n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + p_c[k]) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
         }
-    };
-    // step s -> (item, chunk)
-    auto step_item = [&](int s, int &item, int &ck) {
-        const int li = s / a.n_chunks;
-        ck = s - li * a.n_chunks;
-        item = blockIdx.x + li * gridDim.x;
     };
 
     // my items: blockIdx.x, + gridDim.x, ...; steps = (local item, chunk) linearised
@@ -210,14 +228,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
 
     // prologue: weights of step 0, patches of steps 0 and 1 (issue order matters for the counted waits below:
     // per step the weights of s+1 are issued BEFORE the patch of s+2)
+    Cursor cw, cp;                                        // next weight chunk / next patch chunk to fetch
     if (n_steps > 0) {
-        issue_weights(blockIdx.x, 0, 0);
-        issue_patch(blockIdx.x, 0, 0);
+        cursor_init(cw, 0);
+        cp = cw;
+        issue_weights(cw, 0);
+        issue_patch(cp, 0);
+        cursor_next(cw);                                  // -> step 1
+        cursor_next(cp);
     }
     if (AHEAD == 2 && n_steps > 1) {
-        int it1, ck1;
-        step_item(1, it1, ck1);
-        issue_patch(it1, ck1, 1);
+        issue_patch(cp, 1);
+        cursor_next(cp);                                  // -> step 2
     }
     f32x4 acc[NI][MI];
     int li = 0, ck = 0;                                   // local item index / chunk of the current step
@@ -233,14 +255,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
         int fin_n = -1;
         if (last_chunk && !(a.ablate & 4)) fin_n = epi_prefetch(item);
         if (s + 1 < n_steps) {
-            int it1, ck1;
-            step_item(s + 1, it1, ck1);
-            if (!(a.ablate & 2)) issue_weights(it1, ck1, (s + 1) & 1);
+            if (!(a.ablate & 2)) issue_weights(cw, (s + 1) & 1);
+            if (s + 2 < n_steps) cursor_next(cw);
         }
         if (s + AHEAD < n_steps) {
-            int it2, ck2;
-            step_item(s + AHEAD, it2, ck2);
-            if (!(a.ablate & 2)) issue_patch(it2, ck2, (s + AHEAD) % PD);
+            if (!(a.ablate & 2)) issue_patch(cp, (s + AHEAD) % PD);
+            if (s + AHEAD + 1 < n_steps) cursor_next(cp);
         }
         if (ck == 0) {
 #pragma unroll
@@ -334,6 +354,7 @@ int conv_chunked_launch(fid_ctx *ctx, const ConvArgs &c, int cb) {
     a.n_cblk = cdiv(c.Cout_p, cb);
     a.n_items = a.n_tiles * a.n_cblk;
     a.n_chunks = c.Cin_p / CK;
+    a.d_cblk = fastdiv_make(a.n_cblk); a.d_tpi = fastdiv_make(a.tiles_x * a.tiles_y); a.d_tx = fastdiv_make(a.tiles_x);
     a.in_bytes = c.in_bytes;
     a.w_bytes = std::min<size_t>(c.w_bytes, (size_t)c.w_rows * 9 * c.Cin_p * 2);   // rows past the bank read as 0
     if (const char *e = getenv("FID_CHUNK_ABLATE")) a.ablate = atoi(e);
