@@ -157,20 +157,23 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             const int p = s_pk[k] & 255, c = (s_pk[k] >> 8) & 255, wv = s_pk[k] >> 16;
             s_off[k] = ((((wv & 3) * MI + (p >> 4)) * a.W + (p & 15)) * a.Cout_p + (wv >> 2) * NI * 16 + c * 8) * 2;
         }
-        auto store_tile = [&](int item, char *slot) {           // the tile of `item`, staged in `slot`
-            int n, ty, tx, cb;
-            decode_item(item, n, ty, tx, cb);
-            u32x4 v[MAX_S];
+        u32x4 sv[MAX_S];                                        // my share of a staged tile, between read-back and store
+        auto read_tile = [&](char *slot) {
 #pragma unroll
             for (int k = 0; k < MAX_S; k++)
-                if (pw + N_PROD * k < S_BLKS) v[k] = *(const u32x4 *)(slot + (pw + N_PROD * k) * 1024 + lane * 16);
+                if (pw + N_PROD * k < S_BLKS) sv[k] = *(const u32x4 *)(slot + (pw + N_PROD * k) * 1024 + lane * 16);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read back before my weight DMAs refill the slot
+        };
+        static_assert(S_BLKS % N_PROD == 0, "every producer stores the same number of blocks");
+        auto store_tile = [&](int item) {                       // the tile of `item`, read back into sv; true: exactly MAX_S stores issued
+            int n, ty, tx, cb;
+            decode_item(item, n, ty, tx, cb);
             if (ty * TH + TH <= a.H && tx * TW + TW <= a.W && cb * CB + CB <= a.Cout_p) {   // whole tile inside the tensor
                 char *base = (char *)a.out + ((((size_t)n * a.H + ty * TH) * a.W + tx * TW) * a.Cout_p + cb * CB) * 2;
 #pragma unroll
                 for (int k = 0; k < MAX_S; k++)
-                    if (pw + N_PROD * k < S_BLKS) *(u32x4 *)(base + (unsigned)s_off[k]) = v[k];
-                return;
+                    if (pw + N_PROD * k < S_BLKS) *(u32x4 *)(base + (unsigned)s_off[k]) = sv[k];
+                return true;
             }
 #pragma unroll
             for (int k = 0; k < MAX_S; k++) {
@@ -181,8 +184,9 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
                 const int oy = ty * TH + (wv & 3) * MI + (p >> 4), ox = tx * TW + (p & 15);
                 const int co = cb * CB + (wv >> 2) * NI * 16 + c * 8;
                 if (oy < a.H && ox < a.W && co < a.Cout_p)
-                    *(u32x4 *)((char *)a.out + ((((size_t)n * a.H + oy) * a.W + ox) * a.Cout_p + co) * 2) = v[k];
+                    *(u32x4 *)((char *)a.out + ((((size_t)n * a.H + oy) * a.W + ox) * a.Cout_p + co) * 2) = sv[k];
             }
+            return false;
         };
         struct Cursor {
             int item, ck;      // work item / chunk the NEXT issue of this stream fetches
@@ -254,6 +258,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             cursor_next(cp);                                   // -> step 2
         }
         bool newest_is_patch = AHEAD == 2 && n_steps > 1;      // the youngest P_BLKS DMAs are a patch that may stay in flight
+        bool newest_is_stores = false;                          // the youngest MAX_S entries are output stores
         int ck = 0, item = blockIdx.x;                         // chunk / item of the step the consumers are in
         for (int s = 0; s < n_steps; s++) {
             // everything step s reads must have landed: W(s) and P(s); only a younger patch may stay in flight
@@ -261,7 +266,9 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             if (newest_is_patch) {
                 if (my_p == MAX_P) wait_vmcnt_n<MAX_P>();
                 else wait_vmcnt_n<MAX_P - 1>();
-            } else wait_vmcnt_n<0>();
+            } else if (newest_is_stores) wait_vmcnt_n<MAX_S>();   // the output stores of the step before need not have retired
+            else wait_vmcnt_n<0>();
+            newest_is_stores = false;
             STAMP(0, 1);
             raw_barrier();                                     // T(s)
             STAMP(0, 2);
@@ -272,8 +279,9 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
                 // (barrier F) write it out, then fetch the weights that go into the staging slot
                 if (have_p) issue_patch(cp, (s + AHEAD) % PD);
                 raw_barrier();                                 // F(s)
-                store_tile(item - gridDim.x, sWr + ((s + 1) & 1) * W_BYTES);
-                if (have_w) issue_weights(cw, (s + 1) & 1);
+                read_tile(sWr + ((s + 1) & 1) * W_BYTES);
+                if (have_w) issue_weights(cw, (s + 1) & 1);    // the prefetch first: the stores have a whole step
+                newest_is_stores = store_tile(item - gridDim.x);
                 newest_is_patch = false;
             } else {
                 if (have_w) issue_weights(cw, (s + 1) & 1);
@@ -288,7 +296,8 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         }
         raw_barrier();                                         // tail A: every consumer is done with the last weight slot
         raw_barrier();                                         // tail B: the last tile is staged
-        store_tile(item - gridDim.x, sWr + ((n_steps - 1) & 1) * W_BYTES);
+        read_tile(sWr + ((n_steps - 1) & 1) * W_BYTES);
+        store_tile(item - gridDim.x);
         return;
     }
 
