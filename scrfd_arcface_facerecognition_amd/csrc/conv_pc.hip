@@ -117,16 +117,29 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             const int t = row / CB, co = row - t * CB;
             w_off[k] = ((co * 9 + t) * a.Cin_p + ((lane & 3) ^ swz64(row)) * 8) * 2;
         }
-        int p_pk[MAX_P];                                   // py | px << 8 | channel offset << 16 (py = 255: padding row)
-#pragma unroll
-        for (int k = 0; k < MAX_P; k++) {
-            const int j = pw + N_PROD * k;
-            const int row = j * 16 + (lane >> 2);
+        // py | px << 8 | channel offset << 16 (py = 255: padding row) of my k-th patch block; recomputed where needed (border
+        // tiles only) instead of held in registers: the producers' register budget goes to the tile they carry
+        constexpr bool KEEP_PK = NI <= 2;                   // CB = 64 has the registers to keep them (small maps are all border tiles)
+        auto patch_pk_calc = [&](int k) {
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int row = (pw + N_PROD * k) * 16 + (lo >> 2);
             int py = row / PW;
             const int px = row - py * PW;
             if (row >= NPIX) py = 255;
-            p_pk[k] = py | (px << 8) | ((((lane & 3) ^ swz64(row)) * 8) << 16);
+            return py | (px << 8) | ((((lo & 3) ^ swz64(row)) * 8) << 16);
+        };
+        int p_pk[KEEP_PK ? MAX_P : 1];
+        if (KEEP_PK) {
+#pragma unroll
+            for (int k = 0; k < MAX_P; k++) p_pk[KEEP_PK ? k : 0] = patch_pk_calc(k);
         }
+        auto patch_pk = [&](int k) {
+            if (!KEEP_PK) return patch_pk_calc(k);
+            int pk = p_pk[KEEP_PK ? k : 0];
+            asm volatile("" : "+v"(pk));                       // opaque: unpack at the use, do not hoist three registers per block
+            return pk;
+        };
         const int my_p = (P_BLKS - pw + N_PROD - 1) / N_PROD;   // patch DMAs I issue per chunk (6 or 5)
         // the same blocks for tiles whose whole 18x18 patch lies inside the image: lane offset relative to the patch's
         // top-left pixel, so an issue costs 3 vector instructions instead of ~20 (the producers share their SIMDs' vector
@@ -134,8 +147,8 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         int p_off[MAX_P];
 #pragma unroll
         for (int k = 0; k < MAX_P; k++) {
-            const int py = p_pk[k] & 255, px = (p_pk[k] >> 8) & 255;
-            p_off[k] = py == 255 ? -1 : ((py * a.W + px) * a.Cin_p + (p_pk[k] >> 16)) * 2;
+            const int pk = patch_pk(k), py = pk & 255, px = (pk >> 8) & 255;
+            p_off[k] = py == 255 ? -1 : ((py * a.W + px) * a.Cin_p + (pk >> 16)) * 2;
         }
         // output stores: the consumers stage a finished fp16 tile in the accumulator layout's transpose (wave-major,
         // [64 pixels][NI*32 B], 16-byte chunks swizzled by pixel); the producers read it back as whole 16-byte cout segments and
@@ -143,18 +156,29 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         // that block anyway.  Block b of the staging area = consumer wave b / SK, chunks (b % SK)*64 ... +63.
         constexpr int OCPP = NI * 2, SK = OCPP, S_BLKS = N_CONS * SK, MAX_S = (S_BLKS + N_PROD - 1) / N_PROD;
         constexpr int OMASK = (OCPP & (OCPP - 1)) == 0 ? OCPP - 1 : 0;
-        int s_pk[MAX_S];                                        // pixel | cout chunk << 8 | consumer wave << 16
-#pragma unroll
-        for (int k = 0; k < MAX_S; k++) {
+        auto stage_pk_calc = [&](int k) {                       // pixel | cout chunk << 8 | consumer wave << 16 of my k-th staging block
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
             const int b = pw + N_PROD * k, wv = b / SK;
-            const int gl = (b - wv * SK) * 64 + lane;
+            const int gl = (b - wv * SK) * 64 + lo;
             const int p = gl / OCPP, c = (gl - p * OCPP) ^ (p & OMASK);
-            s_pk[k] = p | (c << 8) | (wv << 16);
+            return p | (c << 8) | (wv << 16);
+        };
+        int s_pk[KEEP_PK ? MAX_S : 1];
+        if (KEEP_PK) {
+#pragma unroll
+            for (int k = 0; k < MAX_S; k++) s_pk[KEEP_PK ? k : 0] = stage_pk_calc(k);
         }
+        auto stage_pk = [&](int k) {
+            if (!KEEP_PK) return stage_pk_calc(k);
+            int pk = s_pk[KEEP_PK ? k : 0];
+            asm volatile("" : "+v"(pk));
+            return pk;
+        };
         int s_off[MAX_S];                                       // byte offset of my segment relative to the tile's first output
 #pragma unroll
         for (int k = 0; k < MAX_S; k++) {
-            const int p = s_pk[k] & 255, c = (s_pk[k] >> 8) & 255, wv = s_pk[k] >> 16;
+            const int pk = stage_pk(k), p = pk & 255, c = (pk >> 8) & 255, wv = pk >> 16;
             s_off[k] = ((((wv & 3) * MI + (p >> 4)) * a.W + (p & 15)) * a.Cout_p + (wv >> 2) * NI * 16 + c * 8) * 2;
         }
         u32x4 sv[MAX_S];                                        // my share of a staged tile, between read-back and store
@@ -163,6 +187,37 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             for (int k = 0; k < MAX_S; k++)
                 if (pw + N_PROD * k < S_BLKS) sv[k] = *(const u32x4 *)(slot + (pw + N_PROD * k) * 1024 + lane * 16);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read back before my weight DMAs refill the slot
+        };
+        // Residual layers: the residual tile travels the other way through the same staging blocks.  The producers load it as
+        // whole 16-byte segments (8 cache lines per instruction; the consumers' accumulator-layout loads were 8 bytes per lane
+        // = 16 lines per instruction, on the path that already limits the step) during the item's last chunk, drop it into
+        // the staging slot at the next step's start, and the consumers read their own elements from LDS.
+        const bool has_res = a.res != nullptr;
+        u32x4 rv[MAX_S];
+        auto load_residual = [&](int item) {
+            int n, ty, tx, cb;
+            decode_item(item, n, ty, tx, cb);
+            if (ty * TH + TH <= a.H && tx * TW + TW <= a.W && cb * CB + CB <= a.Cout_p) {   // whole tile inside the tensor
+                const char *base = (const char *)a.res + ((((size_t)n * a.H + ty * TH) * a.W + tx * TW) * a.Cout_p + cb * CB) * 2;
+#pragma unroll
+                for (int k = 0; k < MAX_S; k++) rv[k] = *(const u32x4 *)(base + (unsigned)s_off[k]);
+                return;
+            }
+#pragma unroll
+            for (int k = 0; k < MAX_S; k++) {
+                const int pk = stage_pk(k);
+                const int p = pk & 255, c = (pk >> 8) & 255, wv = pk >> 16;
+                const int oy = ty * TH + (wv & 3) * MI + (p >> 4), ox = tx * TW + (p & 15);
+                const int co = cb * CB + (wv >> 2) * NI * 16 + c * 8;
+                rv[k] = u32x4{0u, 0u, 0u, 0u};
+                if (oy < a.H && ox < a.W && co < a.Cout_p)
+                    rv[k] = *(const u32x4 *)((const char *)a.res + ((((size_t)n * a.H + oy) * a.W + ox) * a.Cout_p + co) * 2);
+            }
+        };
+        auto write_residual = [&](char *slot) {
+#pragma unroll
+            for (int k = 0; k < MAX_S; k++) *(u32x4 *)(slot + (pw + N_PROD * k) * 1024 + lane * 16) = rv[k];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         static_assert(S_BLKS % N_PROD == 0, "every producer stores the same number of blocks");
         auto store_tile = [&](int item) {                       // the tile of `item`, read back into sv; true: exactly MAX_S stores issued
@@ -178,8 +233,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
 #pragma unroll
             for (int k = 0; k < MAX_S; k++) {
                 if (pw + N_PROD * k >= S_BLKS) continue;
-                int pk = s_pk[k];
-                asm volatile("" : "+v"(pk));
+                const int pk = stage_pk(k);
                 const int p = pk & 255, c = (pk >> 8) & 255, wv = pk >> 16;
                 const int oy = ty * TH + (wv & 3) * MI + (p >> 4), ox = tx * TW + (p & 15);
                 const int co = cb * CB + (wv >> 2) * NI * 16 + c * 8;
@@ -235,8 +289,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             for (int k = 0; k < MAX_P; k++) {
                 const int j = pw + N_PROD * k;
                 if (j >= P_BLKS) continue;
-                int pk = p_pk[k];
-                asm volatile("" : "+v"(pk));                   // opaque: unpack here, do not hoist three registers per block
+                const int pk = patch_pk(k);
                 const int py = pk & 255, iy = c.y0 + py, ix = c.x0 + ((pk >> 8) & 255);
                 const bool in = py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const unsigned vo = in ? (unsigned)((((c.n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
@@ -277,6 +330,10 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             if (flush) {
                 // patch first (its slot is not involved in the staging); after the consumers have staged the previous tile
                 // (barrier F) write it out, then fetch the weights that go into the staging slot
+                if (has_res) {                                 // (loaded during the step before; the wait ahead of T(s) covered them)
+                    write_residual(sWr + ((s + 1) & 1) * W_BYTES);
+                    raw_barrier();                             // R(s): the consumers pick their residual values up
+                }
                 if (have_p) issue_patch(cp, (s + AHEAD) % PD);
                 raw_barrier();                                 // F(s)
                 read_tile(sWr + ((s + 1) & 1) * W_BYTES);
@@ -288,6 +345,11 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
                 if (have_p) issue_patch(cp, (s + AHEAD) % PD);
                 newest_is_patch = AHEAD == 2 && have_p;
             }
+            if (has_res && ck == a.n_chunks - 1) {             // the item's last chunk: fetch its residual tile (after the prefetches)
+                load_residual(item);
+                newest_is_patch = false;                       // the loads are the youngest entries now: next wait is vmcnt(0)
+                newest_is_stores = false;
+            }
             STAMP(0, 3);
             if (have_w && s + 2 < n_steps) cursor_next(cw);
             if (have_p && s + AHEAD + 1 < n_steps) cursor_next(cp);
@@ -295,6 +357,11 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             if (++ck == a.n_chunks) { ck = 0; item += gridDim.x; }
         }
         raw_barrier();                                         // tail A: every consumer is done with the last weight slot
+        if (has_res) {
+            wait_vmcnt_n<0>();
+            write_residual(sWr + ((n_steps - 1) & 1) * W_BYTES);
+            raw_barrier();                                     // tail R
+        }
         raw_barrier();                                         // tail B: the last tile is staged
         read_tile(sWr + ((n_steps - 1) & 1) * W_BYTES);
         store_tile(item - gridDim.x);
@@ -322,7 +389,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         asm volatile("" : "+v"(lo));                         // from being hoisted out of the step loop (and spilled)
         const int frow = lo & 15, fq = lo >> 4;
         const int co_w = cb * CB + grp * NI * 16;            // first cout of this wave
-        if (a.res != nullptr || (a.flags & CF_BORDER)) {     // pixel coordinates: only the residual / border-class bias need them
+        if (a.flags & CF_BORDER) {                           // pixel coordinates: only the border-class bias needs them
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) {
                 const int oy = ty * TH + wg * MI + mi, ox = tx * TW + frow;
@@ -343,15 +410,22 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
                 if (a.act == ACT_PRELU) R.sl[ni] = *(const ep_f32x4 *)(a.slope + c);
             }
         }
-        if (a.res != nullptr) {
+    };
+    f32x4 acc[NI][MI];
+    const bool has_res = a.res != nullptr;
+    auto epi_residual_values = [&](char *slot) {            // residual layers: my residual elements sit where my outputs will go
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const int frow = lo & 15, fq = lo >> 4;
+        const char *sS = slot + wave * (64 * OROWB);
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
-                const size_t roff = px[mi].valid ? (size_t)px[mi].m * a.res_Cp : 0;
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-                for (int ni = 0; ni < NI; ni++)
-                    R.rr[ni][mi] = *(const ep_half4 *)((const _Float16 *)a.res + roff + (co0[ni] < a.Cout_p ? co0[ni] : 0));
+            for (int ni = 0; ni < NI; ni++) {
+                const int p = mi * 16 + frow, c = ni * 2 + (fq >> 1);
+                R.rr[ni][mi] = *(const ep_half4 *)(sS + p * OROWB + ((c ^ (p & OMASK)) << 4) + (fq & 1) * 8);
             }
-        }
+        epilogue_values_fast<NI, MI>(ep, acc, px, co0, R, hv);
     };
     auto epi_stage = [&](char *slot) {                       // fp16 tile: accumulator layout -> LDS, transposed; the producers store it
         int lo = lane;
@@ -368,7 +442,6 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged before the barrier that hands the slot to the producers
     };
 
-    f32x4 acc[NI][MI];
     int li = 0, ck = 0;                                   // local item index / chunk of the current step
     for (int s = 0; s < n_steps; s++) {
         const int item = blockIdx.x + li * gridDim.x;
@@ -377,7 +450,12 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         raw_barrier();                                      // T(s): the producer saw W(s), P(s) land; everyone is done with step s-1
         if (wave == 0 || wave == 7) STAMP(who, 1);
         if (ck == 0 && s > 0) {
-            epi_stage(sWr + ((s + 1) & 1) * W_BYTES);       // into step s-1's weight slot
+            char *slot = sWr + ((s + 1) & 1) * W_BYTES;     // step s-1's weight slot
+            if (has_res) {
+                raw_barrier();                              // R(s): the producers have put the residual tile there
+                epi_residual_values(slot);                  // (the previous item's sums are still in acc)
+            }
+            epi_stage(slot);
             raw_barrier();                                  // F(s): the producers write the tile out, then refill the slot
         }
         if (wave == 0 || wave == 7) STAMP(who, 2);
@@ -424,11 +502,15 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             }
         }
         if (wave == 0 || wave == 7) STAMP(who, 4);
-        if (last_chunk) epilogue_values_fast<NI, MI>(ep, acc, px, co0, R, hv);   // kept in registers until the next step stages them
+        if (last_chunk && !has_res) epilogue_values_fast<NI, MI>(ep, acc, px, co0, R, hv);   // kept in registers until the next step stages them
         if (wave == 0 || wave == 7) STAMP(who, 5);
         if (++ck == a.n_chunks) { ck = 0; li++; }
     }
     raw_barrier();                                          // tail A: all consumers are done reading the last weight slot
+    if (has_res) {
+        raw_barrier();                                      // tail R
+        epi_residual_values(sWr + ((n_steps - 1) & 1) * W_BYTES);
+    }
     epi_stage(sWr + ((n_steps - 1) & 1) * W_BYTES);
     raw_barrier();                                          // tail B: the producers store the last tile
 }
