@@ -50,6 +50,7 @@ struct PCArgs {
     int tiles_x, tiles_per_img, n_cblk, n_items, n_chunks;
     FastDiv d_cblk, d_tpi, d_tx;
     unsigned in_bytes, w_bytes;
+    int ablate;   // timing experiments only (FID_PC_ABLATE: 1 = no weight DMA, 2 = no patch DMA)
 };
 
 // Diagnostic build only (make EXTRA=-DFID_PC_STAMPS): s_memtime stamps of workgroup 0 -- producer, consumer waves 0 and 7.
@@ -261,6 +262,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             }
         };
         auto issue_weights = [&](const Cursor &c, int slot) {
+            if (a.ablate & 1) return;
             const int ubase = c.w_base + c.ck * CK * 2;
             char *dst = sWr + slot * W_BYTES;
 #pragma unroll
@@ -272,6 +274,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             }
         };
         auto issue_patch = [&](const Cursor &c, int slot) {    // exactly my_p instructions (vmcnt accounting)
+            if (a.ablate & 2) return;
             const int c0 = c.ck * CK;
             char *dst = sPr + slot * P_BYTES;
             if (c.y0 >= 0 && c.x0 >= 0 && c.y0 + TH + 2 <= a.H && c.x0 + TW + 2 <= a.W) {   // interior tile
@@ -575,6 +578,7 @@ int conv_pc_launch(fid_ctx *ctx, const ConvArgs &c, int cb) {
     a.d_cblk = fastdiv_make(a.n_cblk); a.d_tpi = fastdiv_make(a.tiles_per_img); a.d_tx = fastdiv_make(a.tiles_x);
     a.in_bytes = c.in_bytes;
     a.w_bytes = (unsigned)std::min<size_t>(c.w_bytes, (size_t)c.w_rows * 9 * c.Cin_p * 2);   // rows past the bank read as 0
+    if (const char *e = getenv("FID_PC_ABLATE")) a.ablate = atoi(e);
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
     if (cb == 64) return launch_pc<2>(ctx, a);
     if (cb == 96) return launch_pc<3>(ctx, a);
