@@ -553,6 +553,149 @@ __global__ void __launch_bounds__(256, (NS * (BM + (BN + 256 / (BK / 8) - 1) / (
     tile_epilogue<BM, BN, WM, WN, NS * STAGE>(a, acc, tm, tn, split, smem);
 }
 
+// ================================================================================================
+// Generation 6: generation 2 with the work split by ROLE (the conv_pc.hip lesson applied to the implicit GEMM).
+// In generation 2 every wave issues its 6-8 LDS-DMA pieces right after the K-step's barrier and only then starts to
+// multiply: a wave blocks in each DMA issue while the CU's address path serves the others (~50 cycles a piece), which
+// is as long as the K-step's 16-32 MFMAs.  Here waves 0..3 (consumers) only read fragments and multiply; waves 4 and 5
+// (producers) issue the whole stage -- each the pieces of two "virtual" generation-2 waves, same LDS image -- and
+// wait for their own DMAs (counted vmcnt) before they join the barrier.
+// ================================================================================================
+template <int BM, int BN, int BK, int NS, int WM, int WN>
+__global__ void __launch_bounds__(384, ((NS * (BM + (BN + 256 / (BK / 8) - 1) / (256 / (BK / 8)) * (256 / (BK / 8))) * BK * 2 <= 80 * 1024) && (BM / WM / 16) * (BN / WN / 16) < 12) ? 3 : 2)
+    conv_mfma_pc_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int ROWB = BK * 2, CPR = BK / 8;
+    constexpr int RPW = 64 / CPR, RPP = 4 * RPW;
+    constexpr int BN_ALLOC = (BN + RPP - 1) / RPP * RPP;
+    constexpr int A_LD = BM / RPP, B_LD = BN_ALLOC / RPP, L = A_LD + B_LD;   // pieces per virtual wave and stage
+    constexpr int STAGE = (BM + BN_ALLOC) * ROWB;
+    static_assert(WM * WN == 4 && BM % RPP == 0 && NS >= 3 && NS <= 4 && NS * STAGE <= 160 * 1024, "tile shape");
+    static_assert((NS - 1) * 2 * L <= 63, "a producer's DMAs in flight must fit the vmcnt counter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    const int Lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tn = Lid % a.tiles_n, tm = Lid / a.tiles_n;
+    const int split = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int ks_begin = split * a.ksteps_per_split;
+    const int ks_end = min(a.ksteps, ks_begin + a.ksteps_per_split);
+    const int nk = ks_end - ks_begin;
+
+    if (wave >= 4) {
+        // ---------------------------------------- producers ----------------------------------------
+        const int pw = wave - 4;
+        const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
+        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+        int a_off[2][A_LD], b_off[2][B_LD];
+        unsigned a_mask[2][A_LD];
+#pragma unroll
+        for (int vw = 0; vw < 2; vw++) {
+            const int lrow = (2 * pw + vw) * RPW + lane / CPR;
+            const int my_chunk = (lane % CPR) ^ swz<BK>(lrow);
+#pragma unroll
+            for (int i = 0; i < A_LD; i++) {
+                const int m = tm * BM + i * RPP + lrow;
+                a_off[vw][i] = 0;
+                a_mask[vw][i] = 0;
+                if (m < a.M) {
+                    const Pix p = decompose(a, m);
+                    const int iy0 = p.oy * a.stride - a.pad, ix0 = p.ox * a.stride - a.pad;
+                    a_off[vw][i] = ((p.n * a.H + iy0) * a.W + ix0) * a.Cin_p + my_chunk * 8;
+                    unsigned mask = 0;
+                    for (int t = 0; t < a.T; t++) {
+                        const int dy = t / a.kw, dx = t - dy * a.kw;
+                        if ((unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W) mask |= 1u << t;
+                    }
+                    a_mask[vw][i] = mask;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; i++) {
+                const int row = i * RPP + lrow, co = tn * BN + row;
+                b_off[vw][i] = (row < BN && co < a.w_rows) ? co * a.T * a.Cin_p + my_chunk * 8 : -1;
+            }
+        }
+        int tap = ks_begin / a.nchunk, ch = ks_begin - tap * a.nchunk;
+        int tdy = tap / a.kw, tdx = tap - tdy * a.kw;
+        auto issue_stage = [&](int slot) {
+            const int adelta = (tdy * a.W + tdx) * a.Cin_p + ch * BK, bdelta = tap * a.Cin_p + ch * BK;
+#pragma unroll
+            for (int vw = 0; vw < 2; vw++) {
+                char *dst = smem + slot * STAGE + (2 * pw + vw) * 1024;
+#pragma unroll
+                for (int j = 0; j < A_LD; j++) {
+                    const unsigned vo = ((a_mask[vw][j] >> tap) & 1u) ? (unsigned)(a_off[vw][j] + adelta) * 2u : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 4096), 16, vo, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < B_LD; i++) {
+                    const unsigned vo = b_off[vw][i] >= 0 ? (unsigned)(b_off[vw][i] + bdelta) * 2u : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void *)(dst + BM * ROWB + i * 4096), 16, vo, 0, 0, 0);
+                }
+            }
+            if (++ch == a.nchunk) {
+                ch = 0;
+                ++tap;
+                if (++tdx == a.kw) { tdx = 0; ++tdy; }
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < NS - 1; s++)
+            if (s < nk) issue_stage(s);
+        for (int k = 0; k < nk; k++) {
+            // stage k must have landed: only the younger stages (at most NS-2 of them) may stay in flight
+            const int younger = min(NS - 2, nk - 1 - k);
+            if (younger >= 2) wait_vmcnt<(NS >= 4 ? 2 : 0) * 2 * L>();
+            else if (younger == 1) wait_vmcnt<2 * L>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();       // stage k landed for everyone; the consumers are done with slot (k-1)%NS
+            if (k + NS - 1 < nk) issue_stage((k + NS - 1) % NS);
+        }
+        __builtin_amdgcn_s_barrier();           // the consumers' barrier before their epilogue
+        return;
+    }
+
+    // ---------------------------------------- consumers ----------------------------------------
+    const int wm = wave / WN, wn = wave % WN;
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr int KK = BK / 32;
+    for (int k = 0; k < nk; k++) {
+        __builtin_amdgcn_s_barrier();
+        const char *cA = smem + (k % NS) * STAGE, *cB = cA + BM * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            half8 wf[NI], pf[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                const int row = wm * TM + mi * 16 + frow;
+                pf[mi] = *(const half8 *)(cA + row * ROWB + (((kk * 4 + fq) ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                const int row = wn * TN + ni * 16 + frow;
+                wf[ni] = *(const half8 *)(cB + row * ROWB + (((kk * 4 + fq) ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // all LDS reads done before the epilogue reuses the ring as staging
+    tile_epilogue<BM, BN, WM, WN, NS * STAGE>(a, acc, tm, tn, split, smem);
+}
+
 // second pass of a split-K conv: sum the slabs in a fixed order (bit-reproducible), then the epilogue
 __global__ void __launch_bounds__(256) splitk_epilogue(const ConvArgs a) {
     const int c4 = a.Cout_p >> 2;
@@ -590,6 +733,20 @@ int launch_dma(fid_ctx *ctx, const ConvArgs &a) {
     }
     dim3 grid(a.tiles_m * a.tiles_n, a.ksplit);
     hipLaunchKernelGGL((conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN, PF>), grid, dim3(256), lds, ctx->stream, a);
+    return FID_OK;
+}
+
+template <int BM, int BN, int BK, int NS, int WM, int WN>
+int launch_pcg(fid_ctx *ctx, const ConvArgs &a) {
+    constexpr int RPP = 4 * (64 / (BK / 8));
+    constexpr size_t lds = (size_t)NS * (BM + (BN + RPP - 1) / RPP * RPP) * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FID_HIP(hipFuncSetAttribute((const void *)conv_mfma_pc_kernel<BM, BN, BK, NS, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, a.ksplit);
+    hipLaunchKernelGGL((conv_mfma_pc_kernel<BM, BN, BK, NS, WM, WN>), grid, dim3(384), lds, ctx->stream, a);
     return FID_OK;
 }
 
@@ -697,16 +854,23 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
             if (ks > 1) { p.ksplit = ks; out.push_back(p); }
         }
     };
+    // Generation 6 (two producer waves per workgroup) is opt-in: measured 30-40 % SLOWER than generation 2 on the large-M
+    // layers (two waves cannot issue a stage's 16-32 DMA pieces in a K-step's 256-512 MFMA cycles: ~75 cycles per piece and
+    // wave) and 5-12 % faster only on the 64-face 14x14 / 7x7 layers, which the halo-patch kernels serve better anyway.
+    const char *fg6 = getenv("FID_FORCE_GEN");
+    const bool gemm_pc = getenv("FID_GEMM_PC") != nullptr || (fg6 && atoi(fg6) == 6);
     if (bk == 64) {
         for (int gen = 1; gen <= 2; gen++) {
             add(gen, 128, 128, 4); add(gen, 128, 64, 4); add(gen, 64, 64, 4);
         }
         add(2, 128, 128, 3); add(2, 128, 64, 3); add(2, 64, 64, 3);
         add(2, 128, 128, 5); add(2, 128, 64, 5); add(2, 64, 64, 5);   // ns = 5: 4 slots + fragment prefetch across K-steps
+        if (gemm_pc) { add(6, 128, 128, 4); add(6, 128, 64, 4); add(6, 64, 64, 4); add(6, 128, 64, 3); add(6, 64, 64, 3); }
     } else {
         for (int gen = 1; gen <= 2; gen++) {
             add(gen, 128, 128, 4); add(gen, 128, 96, 4); add(gen, 128, 64, 4); add(gen, 128, 32, 4);
         }
+        if (gemm_pc) { add(6, 128, 128, 4); add(6, 128, 96, 4); add(6, 128, 64, 4); }
     }
     if (out.empty()) out.push_back(conv_plan(a, num_cus, false));
     for (auto &p : out) p.partial_bytes = p.ksplit > 1 ? (size_t)p.ksplit * a.M * a.Cout_p * 4 : 0;
@@ -732,7 +896,20 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     a.tiles_n = cdiv(a.Cout_p, plan.bn);
     FID_REQUIRE(a.ksplit == 1 || a.partial, "conv: split-K without a partial buffer");
     int rc = FID_E_INVALID;
-    if (plan.gen == 2) {
+    if (plan.gen == 6) {
+        const int key = (plan.bm * 1000 + plan.bn) * 1000 + plan.bk * 10 + plan.ns;
+        switch (key) {
+            case 128128644: rc = launch_pcg<128, 128, 64, 4, 2, 2>(ctx, a); break;
+            case 128064644: rc = launch_pcg<128, 64, 64, 4, 2, 2>(ctx, a); break;
+            case 128064643: rc = launch_pcg<128, 64, 64, 3, 2, 2>(ctx, a); break;
+            case 64064644: rc = launch_pcg<64, 64, 64, 4, 2, 2>(ctx, a); break;
+            case 64064643: rc = launch_pcg<64, 64, 64, 3, 2, 2>(ctx, a); break;
+            case 128128324: rc = launch_pcg<128, 128, 32, 4, 2, 2>(ctx, a); break;
+            case 128096324: rc = launch_pcg<128, 96, 32, 4, 2, 2>(ctx, a); break;
+            case 128064324: rc = launch_pcg<128, 64, 32, 4, 2, 2>(ctx, a); break;
+            default: set_error("conv: no producer/consumer GEMM kernel for tile %dx%dx%d ns=%d", plan.bm, plan.bn, plan.bk, plan.ns); return FID_E_INVALID;
+        }
+    } else if (plan.gen == 2) {
         const int key = (plan.bm * 1000 + plan.bn) * 1000 + plan.bk * 10 + plan.ns;
         switch (key) {
             case 128128644: rc = launch_dma<128, 128, 64, 4, 2, 2>(ctx, a); break;
