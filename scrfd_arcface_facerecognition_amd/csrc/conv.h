@@ -34,7 +34,7 @@ struct ConvArgs {
 // must hold ksplit*M*Cout_p floats when the plan splits K (query with conv_plan first).
 struct ConvPlan {
     int bm, bn, bk, ksplit;
-    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves
+    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr
     int ns;    // ring slots (gen 2); 5 = 4 slots + fragment prefetch across K-steps
     size_t partial_bytes;
 };
@@ -60,6 +60,10 @@ int conv_pp_launch(fid_ctx *ctx, const ConvArgs &a, int cb);
 // conv_pc.hip: conv_chunked's data flow with a dedicated producer wave (DMA issue + prefetch decode) beside 8 MFMA waves; cb = 64 | 96
 bool conv_pc_applicable(const ConvArgs &a);
 int conv_pc_launch(fid_ctx *ctx, const ConvArgs &a, int cb);
+
+// conv_pcr.hip: 64 -> 64 channels, weights resident in LDS, 8 MFMA waves on one tile + 4 producer waves
+bool conv_pcr_applicable(const ConvArgs &a);
+int conv_pcr_launch(fid_ctx *ctx, const ConvArgs &a);
 
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,

@@ -1,4 +1,4 @@
-"""GPU parity: every conv kernel family (direct, gen-1 igemm, gen-2 LDS-DMA ring, channel-chunked direct, ping-pong chunked, producer/consumer chunked, producer/consumer implicit GEMM),
+"""GPU parity: every conv kernel family (direct, gen-1 igemm, gen-2 LDS-DMA ring, channel-chunked direct, ping-pong chunked, producer/consumer chunked, producer/consumer implicit GEMM, producer/consumer resident-weight 64-channel conv),
 forced through the autotuner hook FID_FORCE_GEN, against the fp32 oracle on the same layer stacks."""
 import numpy as np
 import pytest
@@ -30,8 +30,8 @@ def stack(hw, chans, res=True):
     return net
 
 
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 25])  # 25 = generation 2 with ns = 5 (fragment prefetch across K-steps)
-@pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2)])
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 25])  # 25 = generation 2 with ns = 5 (fragment prefetch across K-steps)
+@pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2), ((37, 21), (64, 64), 3)])
 def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     if gen == 25:
