@@ -59,7 +59,7 @@ int conv_pp_launch(fid_ctx *ctx, const ConvArgs &a, int cb);
 
 // conv_pc.hip: conv_chunked's data flow with a dedicated producer wave (DMA issue + prefetch decode) beside 8 MFMA waves; cb = 64 | 96
 bool conv_pc_applicable(const ConvArgs &a);
-int conv_pc_launch(fid_ctx *ctx, const ConvArgs &a, int cb);
+int conv_pc_launch(fid_ctx *ctx, const ConvArgs &a, int cb, int ring);
 
 // conv_pcr.hip: 64 -> 64 channels, weights resident in LDS, 8 MFMA waves on one tile + 4 producer waves
 bool conv_pcr_applicable(const ConvArgs &a);

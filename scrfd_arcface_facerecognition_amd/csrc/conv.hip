@@ -825,7 +825,10 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
     if (conv_pc_applicable(a)) {
         ConvPlan d{};
         d.gen = 5; d.ksplit = 1; d.bm = 256; d.bk = 32;
-        d.bn = 64; out.push_back(d);
+        d.bn = 64; d.ns = 0; out.push_back(d);
+        // weights two steps ahead instead of patches: measured equal or 1-2 % slower everywhere; kept for tests / experiments
+        if (getenv("FID_FORCE_NS")) { d.ns = 1; out.push_back(d); }
+        d.ns = 0;
         if (a.Cout_p % 96 == 0) { d.bn = 96; out.push_back(d); }
     }
     if (conv_pp_applicable(a)) {
@@ -882,7 +885,7 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 0) return conv_direct_launch(ctx, a);
     if (plan.gen == 3) return conv_chunked_launch(ctx, a, plan.bn);
     if (plan.gen == 4) return conv_pp_launch(ctx, a, plan.bn);
-    if (plan.gen == 5) return conv_pc_launch(ctx, a, plan.bn);
+    if (plan.gen == 5) return conv_pc_launch(ctx, a, plan.bn, plan.ns);
     if (plan.gen == 7) return conv_pcr_launch(ctx, a);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);

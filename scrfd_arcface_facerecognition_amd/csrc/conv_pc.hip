@@ -76,15 +76,28 @@ __device__ __forceinline__ void wait_vmcnt_n() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NI>   // couts per consumer wave = NI*16; per workgroup CB = 2*NI*16
+// wait until at most n of this wave's memory operations are outstanding (n = a small run-time count, immediate operand)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    switch (n) {
+#define FID_W(k) case k: wait_vmcnt_n<k>(); break;
+        FID_W(1) FID_W(2) FID_W(3) FID_W(4) FID_W(5) FID_W(6) FID_W(7) FID_W(8) FID_W(9) FID_W(10) FID_W(11) FID_W(12)
+        FID_W(13) FID_W(14) FID_W(15) FID_W(16) FID_W(17) FID_W(18) FID_W(19) FID_W(20) FID_W(21) FID_W(22) FID_W(23) FID_W(24)
+#undef FID_W
+        default: wait_vmcnt_n<0>(); break;
+    }
+}
+
+// NI: couts per consumer wave = NI*16 (workgroup CB = 2*NI*16).  WD / PD: ring depths of the weight / patch chunks; a stream
+// with depth 3 is fetched two steps ahead (its youngest chunk may still be in flight at the step's barrier), depth 2 one
+// step ahead.  CB = 96 only fits 2 + 2; CB = 64 fits 2 + 3 (patches, HBM, two ahead) or 3 + 2 (weights two ahead).
+template <int NI, int WD, int PD>
 __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PCArgs a) {
     constexpr int CB = 2 * NI * 16, MI = 4;
     constexpr int W_BLKS = 9 * CB * 64 / 1024, W_BYTES = W_BLKS * 1024;
-    constexpr int PD = (2 * W_BYTES + 3 * P_BYTES <= 160 * 1024) ? 3 : 2;   // patch ring depth
-    constexpr int AHEAD = PD - 1;                                           // patches are fetched AHEAD steps early, weights 1
-    static_assert(2 * W_BYTES + PD * P_BYTES <= 160 * 1024, "LDS budget");
+    constexpr int AW = WD - 1, AP = PD - 1;             // look-ahead of the two streams, in steps
+    static_assert(WD * W_BYTES + PD * P_BYTES <= 160 * 1024 && !(WD == 3 && PD == 3), "LDS budget");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sWr = smem, *sPr = smem + 2 * W_BYTES;
+    char *sWr = smem, *sPr = smem + WD * W_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // my items: blockIdx.x, + gridDim.x, ...; steps = (local item, chunk) linearised
@@ -300,7 +313,8 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             }
         };
 
-        // prologue: W(0), P(0) [, P(1)]
+        const int my_w = (W_BLKS - pw + N_PROD - 1) / N_PROD;   // weight DMAs I issue per chunk
+        // prologue: everything step 0 reads, then the two-ahead stream's chunk of step 1
         Cursor cw, cp;
         cw.item = blockIdx.x; cw.ck = 0;
         cursor_decode(cw);
@@ -309,64 +323,65 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         issue_patch(cp, 0);
         cursor_next(cw);                                       // -> step 1
         cursor_next(cp);
-        if (AHEAD == 2 && n_steps > 1) {
-            issue_patch(cp, 1);
-            cursor_next(cp);                                   // -> step 2
+        int young = 0;                                         // my youngest memory operations that need not have landed at the next barrier
+        if (n_steps > 1) {
+            if (AP == 2) { issue_patch(cp, 1); cursor_next(cp); young = my_p; }
+            if (AW == 2) { issue_weights(cw, 1); cursor_next(cw); young = my_w; }
         }
-        bool newest_is_patch = AHEAD == 2 && n_steps > 1;      // the youngest P_BLKS DMAs are a patch that may stay in flight
-        bool newest_is_stores = false;                          // the youngest MAX_S entries are output stores
         int ck = 0, item = blockIdx.x;                         // chunk / item of the step the consumers are in
         for (int s = 0; s < n_steps; s++) {
-            // everything step s reads must have landed: W(s) and P(s); only a younger patch may stay in flight
+            // everything step s reads must have landed: W(s) and P(s); only `young` younger operations may stay in flight
             STAMP(0, 0);
-            if (newest_is_patch) {
-                if (my_p == MAX_P) wait_vmcnt_n<MAX_P>();
-                else wait_vmcnt_n<MAX_P - 1>();
-            } else if (newest_is_stores) wait_vmcnt_n<MAX_S>();   // the output stores of the step before need not have retired
-            else wait_vmcnt_n<0>();
-            newest_is_stores = false;
+            wait_vmcnt_dyn(young);
             STAMP(0, 1);
             raw_barrier();                                     // T(s)
             STAMP(0, 2);
             const bool flush = ck == 0 && s > 0;               // the consumers write out the previous tile first
-            const bool have_w = s + 1 < n_steps, have_p = s + AHEAD < n_steps;
+            const bool have_w = s + AW < n_steps, have_p = s + AP < n_steps;
+            char *stage = sWr + ((s + WD - 1) % WD) * W_BYTES; // step s-1's weight slot = where W(s+AW) goes
+            young = 0;
             if (flush) {
                 // patch first (its slot is not involved in the staging); after the consumers have staged the previous tile
-                // (barrier F) write it out, then fetch the weights that go into the staging slot
+                // (barrier F) read it back, fetch the weights that go into the staging slot, then write the tile out
                 if (has_res) {                                 // (loaded during the step before; the wait ahead of T(s) covered them)
-                    write_residual(sWr + ((s + 1) & 1) * W_BYTES);
+                    write_residual(stage);
                     raw_barrier();                             // R(s): the consumers pick their residual values up
                 }
-                if (have_p) issue_patch(cp, (s + AHEAD) % PD);
+                if (have_p) issue_patch(cp, (s + AP) % PD);
                 raw_barrier();                                 // F(s)
-                read_tile(sWr + ((s + 1) & 1) * W_BYTES);
-                if (have_w) issue_weights(cw, (s + 1) & 1);    // the prefetch first: the stores have a whole step
-                newest_is_stores = store_tile(item - gridDim.x);
-                newest_is_patch = false;
+                read_tile(stage);
+                if (have_w) issue_weights(cw, (s + AW) % WD);  // the prefetch first: the stores have a whole step
+                const bool all_stores = store_tile(item - gridDim.x);
+                // youngest first: [stores][W(s+AW)][P(s+AP)]: the stores may always fly on, the weights if they are two ahead
+                if (all_stores) young = MAX_S + ((AW == 2 && have_w) ? my_w : 0);
             } else {
-                if (have_w) issue_weights(cw, (s + 1) & 1);
-                if (have_p) issue_patch(cp, (s + AHEAD) % PD);
-                newest_is_patch = AHEAD == 2 && have_p;
+                // the one-ahead stream first, the two-ahead stream's chunk is the youngest and may stay in flight
+                if (AW == 2) {
+                    if (have_p) issue_patch(cp, (s + AP) % PD);
+                    if (have_w) { issue_weights(cw, (s + AW) % WD); young = my_w; }
+                } else {
+                    if (have_w) issue_weights(cw, (s + AW) % WD);
+                    if (have_p) { issue_patch(cp, (s + AP) % PD); young = AP == 2 ? my_p : 0; }
+                }
             }
             if (has_res && ck == a.n_chunks - 1) {             // the item's last chunk: fetch its residual tile (after the prefetches)
                 load_residual(item);
-                newest_is_patch = false;                       // the loads are the youngest entries now: next wait is vmcnt(0)
-                newest_is_stores = false;
+                young = 0;                                     // the loads are the youngest entries and are needed right after T(s+1)
             }
             STAMP(0, 3);
-            if (have_w && s + 2 < n_steps) cursor_next(cw);
-            if (have_p && s + AHEAD + 1 < n_steps) cursor_next(cp);
+            if (have_w && s + AW + 1 < n_steps) cursor_next(cw);
+            if (have_p && s + AP + 1 < n_steps) cursor_next(cp);
             STAMP(0, 4);
             if (++ck == a.n_chunks) { ck = 0; item += gridDim.x; }
         }
         raw_barrier();                                         // tail A: every consumer is done with the last weight slot
         if (has_res) {
             wait_vmcnt_n<0>();
-            write_residual(sWr + ((n_steps - 1) & 1) * W_BYTES);
+            write_residual(sWr + ((n_steps - 1) % WD) * W_BYTES);
             raw_barrier();                                     // tail R
         }
         raw_barrier();                                         // tail B: the last tile is staged
-        read_tile(sWr + ((n_steps - 1) & 1) * W_BYTES);
+        read_tile(sWr + ((n_steps - 1) % WD) * W_BYTES);
         store_tile(item - gridDim.x);
         return;
     }
@@ -453,7 +468,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         raw_barrier();                                      // T(s): the producer saw W(s), P(s) land; everyone is done with step s-1
         if (wave == 0 || wave == 7) STAMP(who, 1);
         if (ck == 0 && s > 0) {
-            char *slot = sWr + ((s + 1) & 1) * W_BYTES;     // step s-1's weight slot
+            char *slot = sWr + ((s + WD - 1) % WD) * W_BYTES;   // step s-1's weight slot
             if (has_res) {
                 raw_barrier();                              // R(s): the producers have put the residual tile there
                 epi_residual_values(slot);                  // (the previous item's sums are still in acc)
@@ -471,7 +486,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
 #pragma unroll
                 for (int mi = 0; mi < MI; mi++) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const char *sW = sWr + (s & 1) * W_BYTES, *sP = sPr + (s % PD) * P_BYTES;
+        const char *sW = sWr + (s % WD) * W_BYTES, *sP = sPr + (s % PD) * P_BYTES;
         // row-sharing tap order (conv_chunked.hip): column dx, then the 6 patch rows of this wave; a pixel fragment
         // (row r, shift dx) feeds every output row mi = r - dy; the column's three taps keep their weights in registers
         {
@@ -512,23 +527,22 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
     raw_barrier();                                          // tail A: all consumers are done reading the last weight slot
     if (has_res) {
         raw_barrier();                                      // tail R
-        epi_residual_values(sWr + ((n_steps - 1) & 1) * W_BYTES);
+        epi_residual_values(sWr + ((n_steps - 1) % WD) * W_BYTES);
     }
-    epi_stage(sWr + ((n_steps - 1) & 1) * W_BYTES);
+    epi_stage(sWr + ((n_steps - 1) % WD) * W_BYTES);
     raw_barrier();                                          // tail B: the producers store the last tile
 }
 
-template <int NI>
+template <int NI, int WD, int PD>
 int launch_pc(fid_ctx *ctx, const PCArgs &a) {
-    constexpr size_t wb = (size_t)9 * 2 * NI * 16 * 64;
-    constexpr size_t lds = 2 * wb + ((2 * wb + 3 * P_BYTES <= 160 * 1024) ? 3 : 2) * P_BYTES;
+    constexpr size_t lds = (size_t)WD * 9 * 2 * NI * 16 * 64 + (size_t)PD * P_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pc<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pc<NI, WD, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int grid = std::min(a.n_items, ctx->num_cus);
-    hipLaunchKernelGGL((conv3x3_pc<NI>), dim3(grid), dim3((N_CONS + N_PROD) * 64), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv3x3_pc<NI, WD, PD>), dim3(grid), dim3((N_CONS + N_PROD) * 64), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());
 #ifdef FID_PC_STAMPS
     if (const char *e = getenv("FID_PC_STAMP_DUMP")) {
@@ -563,8 +577,9 @@ bool conv_pc_applicable(const ConvArgs &a) {
            (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo));
 }
 
-// cb: output channels per work item (64 or 96)
-int conv_pc_launch(fid_ctx *ctx, const ConvArgs &c, int cb) {
+// cb: output channels per work item (64 or 96); ring: 0 = patches two steps ahead (CB = 64) / both one ahead (CB = 96),
+// 1 = weights two steps ahead (CB = 64 only)
+int conv_pc_launch(fid_ctx *ctx, const ConvArgs &c, int cb, int ring) {
     PCArgs a{};
     a.in = c.in; a.w = c.w; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
@@ -580,8 +595,9 @@ int conv_pc_launch(fid_ctx *ctx, const ConvArgs &c, int cb) {
     a.w_bytes = (unsigned)std::min<size_t>(c.w_bytes, (size_t)c.w_rows * 9 * c.Cin_p * 2);   // rows past the bank read as 0
     if (const char *e = getenv("FID_PC_ABLATE")) a.ablate = atoi(e);
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
-    if (cb == 64) return launch_pc<2>(ctx, a);
-    if (cb == 96) return launch_pc<3>(ctx, a);
+    if (cb == 64 && ring == 1) return launch_pc<2, 3, 2>(ctx, a);
+    if (cb == 64) return launch_pc<2, 2, 3>(ctx, a);
+    if (cb == 96) return launch_pc<3, 2, 2>(ctx, a);
     set_error("producer/consumer conv: cb=%d unsupported", cb);
     return FID_E_INVALID;
 }

@@ -229,10 +229,10 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                         if (c.gen == atoi(fg)) only.push_back(c);
                     if (!only.empty()) cands = only;
                 }
-                if (const char *fn = getenv("FID_FORCE_NS")) {       // tests: one ring variant of generation 2
+                if (const char *fn = getenv("FID_FORCE_NS")) {       // tests: one ring variant of generation 2 / 5
                     std::vector<ConvPlan> only;
                     for (const ConvPlan &c : cands)
-                        if (c.gen == 2 && c.ns == atoi(fn)) only.push_back(c);
+                        if ((c.gen == 2 || c.gen == 5) && c.ns == atoi(fn)) only.push_back(c);
                     if (!only.empty()) cands = only;
                 }
                 hipEvent_t e0, e1;

@@ -30,13 +30,14 @@ def stack(hw, chans, res=True):
     return net
 
 
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 25])  # 25 = generation 2 with ns = 5 (fragment prefetch across K-steps)
+# 25 = generation 2 with ns = 5 (fragment prefetch across K-steps), 51 = generation 5 with the weights two steps ahead
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 25, 51])
 @pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2), ((37, 21), (64, 64), 3)])
 def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
-    if gen == 25:
-        monkeypatch.setenv("FID_FORCE_GEN", "2")
-        monkeypatch.setenv("FID_FORCE_NS", "5")
+    if gen in (25, 51):
+        monkeypatch.setenv("FID_FORCE_GEN", str(gen // 10))
+        monkeypatch.setenv("FID_FORCE_NS", str(gen % 10))
     else:
         monkeypatch.setenv("FID_FORCE_GEN", str(gen))
     net = stack(hw, chans)
