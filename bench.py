@@ -103,7 +103,7 @@ def mfma_roofline(pipe, frames_dev, batch, F):
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
             "kernel": "MFMA conv kernels of one step: conv_mfma_kernel<*> / conv_mfma_dma_kernel<*> / conv3x3_direct<*> / "
-                      "conv3x3_chunked<*> / conv3x3_pc<*> / scrfd_stem_fused<*> (per layer the autotuner's pick)", "launches": launches,
+                      "conv3x3_chunked<*> / conv3x3_pc<*> / conv3x3_pcr / scrfd_stem_fused<*> (per layer the autotuner's pick)", "launches": launches,
             "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2), "gflop_per_step": round(tot_flop / 1e9, 1),
             "per_net": per_net}
 
