@@ -190,9 +190,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, pf, acc, 0, 0, 0);
                 const f32x4 b = bias0[ni];
-                half4 h;
-#pragma unroll
-                for (int i = 0; i < 4; i++) h[i] = inside ? (_Float16)fmaxf(acc[i] + b[i], 0.f) : (_Float16)0.f;
+                half4 h = __builtin_elementwise_max(__builtin_convertvector(acc + b, half4), half4{0, 0, 0, 0});   // ReLU after the rounding: same result
+                if (!inside) h = half4{0, 0, 0, 0};
                 if (qd < N0) *(half4 *)(sO0 + qd * 64 + (((ni * 2 + (fq >> 1)) ^ swz64(qd)) << 4) + (fq & 1) * 8) = h;
             }
         }
@@ -246,9 +245,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++) {
                     const f32x4 b = bias1[ni];
-                    half4 h;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) h[i] = inside[mi] ? (_Float16)fmaxf(acc[ni][mi][i] + b[i], 0.f) : (_Float16)0.f;
+                    half4 h = __builtin_elementwise_max(__builtin_convertvector(acc[ni][mi] + b, half4), half4{0, 0, 0, 0});
+                    if (!inside[mi]) h = half4{0, 0, 0, 0};
                     *(half4 *)(sO1 + qd[mi] * 64 + (((ni * 2 + (fq >> 1)) ^ swz64(qd[mi])) << 4) + (fq & 1) * 8) = h;
                 }
             }
@@ -305,9 +303,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
 #pragma unroll
                 for (int ni = 0; ni < NI2; ni++) {
                     const f32x4 b = bias2[ni];
-                    half4 h;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) h[i] = inside[mi] ? (_Float16)fmaxf(acc[ni][mi][i] + b[i], 0.f) : (_Float16)0.f;
+                    half4 h = __builtin_elementwise_max(__builtin_convertvector(acc[ni][mi] + b, half4), half4{0, 0, 0, 0});
+                    if (!inside[mi]) h = half4{0, 0, 0, 0};
                     const int chunk = ni * 2 + (fq >> 1);
                     const int sw = ROW2 == 128 ? swz128(qd[mi]) : swz64(qd[mi]);
                     *(half4 *)(sO2 + qd[mi] * ROW2 + ((chunk ^ sw) << 4) + (fq & 1) * 8) = h;
@@ -333,8 +330,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
                         const int q = (2 * py + dy) * R2 + (2 * px + dx);
                         const int sw = ROW2 == 128 ? swz128(q) : swz64(q);
                         const half8 v = *(const half8 *)(sO2 + q * ROW2 + ((c ^ sw) << 4));
-#pragma unroll
-                        for (int e = 0; e < 8; e++) m[e] = v[e] > m[e] ? v[e] : m[e];
+                        m = __builtin_elementwise_max(m, v);       // v_pk_max_f16 x 4 (all values are finite and >= 0)
                     }
                 if (gy < a.Hp && gx < a.Wp) *(half8 *)(a.out + (((size_t)n * a.Hp + gy) * a.Wp + gx) * C2P + c * 8) = m;
             }
