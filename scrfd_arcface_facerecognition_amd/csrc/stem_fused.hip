@@ -52,7 +52,8 @@ __device__ __forceinline__ int swz128(int lin) { return lin & 7; }
 template <int C2P, int NW>
 __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemArgs a) {
     constexpr int NT = NW * 64;   // threads per workgroup
-    constexpr int INP_HALFS = RI * RI * 3;              // 5547, + 1 zero element
+    constexpr int RS = 132;                             // halfs per patch row in LDS: the 33-dword window as fetched (3 bytes of lead-in)
+    constexpr int INP_HALFS = RI * RS;                  // 5676, + 1 zero element
     constexpr int INP_BYTES = (INP_HALFS * 2 + 2 + 255) / 256 * 256;
     constexpr int O0_BYTES = ((N0 + 15) / 16 * 16) * 64;  // 448 rows
     constexpr int O1_BYTES = ((N1 + 15) / 16 * 16) * 64;  // 368 rows
@@ -116,22 +117,24 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
         const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
         const int iy0 = 2 * (2 * ty * TP - 3) - 1, ix0 = 2 * (2 * tx * TP - 3) - 1;
+        (void)n;
+        // window element w (= byte of the dword window) holds pixel (w - 3) / 3 of the patch row; it lies inside the frame
+        // for w in [wlo, whi).  Each dword becomes four consecutive halfs: ONE 8-byte LDS store instead of four 2-byte ones.
+        const int wlo = 3 + 3 * max(0, -ix0), whi = 3 + 3 * min(RI, a.W - ix0);
 #pragma unroll
         for (int i = 0; i < DPT; i++) {
             const int d = tid + NT * i;
             if (d < NDW) {
                 const int pr = d / DROW, dc = d - pr * DROW;
                 const bool rin = (unsigned)(iy0 + pr) < (unsigned)a.H;
+                half4 h;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int e = dc * 4 + j - 3;          // element (pixel*3 + channel) inside the patch row
-                    if (e >= 0 && e < RI * 3) {
-                        const int pc = e / 3;
-                        const bool in = rin && (unsigned)(ix0 + pc) < (unsigned)a.W;
-                        const int v = (pre[i] >> (8 * j)) & 0xFF;
-                        sIn[pr * (RI * 3) + e] = in ? (_Float16)(float)(2 * v - 255) : (_Float16)0.f;
-                    }
+                    const int w = dc * 4 + j;
+                    const int v = (pre[i] >> (8 * j)) & 0xFF;
+                    h[j] = (rin && w >= wlo && w < whi) ? (_Float16)(float)(2 * v - 255) : (_Float16)0.f;
                 }
+                *(half4 *)(sIn + pr * RS + dc * 4) = h;
             }
         }
     };
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
     for (int j = 0; j < 8; j++) {
         const int k = fq * 8 + j;
         const int tap = k / 3, c = k - tap * 3, dy = tap / 3, dx = tap - dy * 3;
-        koff[j] = k < 27 ? (dy * RI + dx) * 3 + c : -1;
+        koff[j] = k < 27 ? dy * RS + dx * 3 + c : -1;
     }
 
     // biases in registers for the workgroup's lifetime: read inside the tile loop they are a global load + full wait per
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
         for (int sub = wave; sub < (N0 + 15) / 16; sub += NW) {
             const int q = min(sub * 16 + frow, N0 - 1);
             const int y = q / R0, x = q - y * R0;
-            const int base = (2 * y * RI + 2 * x) * 3;
+            const int base = 2 * y * RS + 2 * x * 3 + 3;
             half8 pf;
 #pragma unroll
             for (int j = 0; j < 8; j++) pf[j] = sIn[koff[j] >= 0 ? base + koff[j] : INP_HALFS];
@@ -341,7 +344,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) scrfd_stem_fused(const StemAr
 
 template <int C2P, int NW>
 int launch_stem(fid_ctx *ctx, const StemArgs &a) {
-    constexpr int INP_BYTES = ((RI * RI * 3) * 2 + 2 + 255) / 256 * 256;
+    constexpr int INP_BYTES = ((RI * 132) * 2 + 2 + 255) / 256 * 256;
     constexpr size_t lds = INP_BYTES + ((N0 + 15) / 16 * 16) * 64 + ((N1 + 15) / 16 * 16) * 64 + ((N2 + 15) / 16 * 16) * (C2P * 2) +
                            32 * 64 + 9 * C1P * 64 + 9 * C2P * 64;
     static bool attr_set = false;
