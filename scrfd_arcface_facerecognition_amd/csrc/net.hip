@@ -82,6 +82,115 @@ __global__ void __launch_bounds__(256) stem_conv3x3(const uint8_t *__restrict__ 
     for (int c = 0; c < CPW; c += 8) *(half8 *)(o + c) = *(half8 *)(res + c);
 }
 
+// ---- first conv of a net on the matrix cores: uint8 frame -> 3x3 conv (K = 27 padded to 32) -> bias/act -> fp16 NHWC ----
+// The VALU kernel above does 27 FMAs per output value (31 TFLOP/s on the IResNet stem: 90 us for 64 faces, 5 % of the net).
+// Here a workgroup walks 16x16-pixel output tiles: the haloed uint8 patch is fetched as aligned dwords of the frame rows,
+// stored as exact integers 2p-255 in fp16 (outside the frame = 0, the blob's zero padding), each wave gathers the K = 27
+// operand of 16 pixels at a time (k = dy*9 + dx*3 + c: nine consecutive elements per patch row) for one
+// v_mfma_f32_16x16x32_f16 per 16 output channels; results leave through a per-wave LDS transpose as 16-byte stores.
+// Weights: the op's fp32 [Cout_p][27] rows (scale and BatchNorm folded by lower.py), rounded to fp16 once per workgroup.
+typedef _Float16 sm_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sm_half4 __attribute__((ext_vector_type(4)));
+typedef float sm_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sm_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NI, int STRIDE>
+__global__ void __launch_bounds__(256) stem_conv_mfma(const uint8_t *__restrict__ img, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, const float *__restrict__ slope,
+                                                      _Float16 *__restrict__ out, int H, int W, int Ho, int Wo, int act,
+                                                      int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int CP = NI * 16, TS = 16;                     // output channels (padded), tile edge
+    constexpr int PR = (TS - 1) * STRIDE + 3;                // patch rows = patch pixel columns (18 / 33)
+    constexpr int ND = (PR * 3 + 1 + 3) / 4;                 // dwords per patch row: 1 byte of lead-in (the window is dword aligned)
+    constexpr int RSH = ND * 4;                              // halfs per patch row in LDS
+    constexpr int OROWB = CP * 2, CPP = OROWB / 16;          // bytes / 16-byte chunks per output pixel
+    __shared__ __attribute__((aligned(16))) _Float16 sIn[PR * RSH + 8];
+    __shared__ __attribute__((aligned(16))) _Float16 sWt[CP * 32];
+    __shared__ __attribute__((aligned(16))) char sSt[4 * TS * OROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+
+    for (int i = tid; i < CP * 32; i += 256) {
+        const int co = i >> 5, k = i & 31;
+        sWt[i] = k < 27 ? (_Float16)w[co * 27 + k] : (_Float16)0.f;
+    }
+    if (tid < 8) sIn[PR * RSH + tid] = (_Float16)0.f;         // the "k >= 27" element
+    __syncthreads();
+    sm_half8 wf[NI];
+    sm_f32x4 bv[NI], sl[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+        wf[ni] = *(const sm_half8 *)(sWt + (ni * 16 + frow) * 32 + fq * 8);
+        bv[ni] = bias ? *(const sm_f32x4 *)(bias + ni * 16 + fq * 4) : sm_f32x4{0.f, 0.f, 0.f, 0.f};
+        sl[ni] = act == ACT_PRELU ? *(const sm_f32x4 *)(slope + ni * 16 + fq * 4) : sm_f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    int koff[8];                                              // k = fq*8 + j -> element offset from the pixel's patch base
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = fq * 8 + j, dy = k / 9, rem = k - dy * 9;
+        koff[j] = k < 27 ? dy * RSH + rem : -1;
+    }
+    const int tiles_per_img = tiles_x * tiles_y, rowbytes = W * 3;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int iy0 = ty * TS * STRIDE - 1, ix0 = tx * TS * STRIDE - 1;
+        const int bx0 = ix0 * 3 - 1;                          // dword-aligned window start (48*STRIDE*tx - 4)
+        const uint8_t *base = img + (size_t)n * H * rowbytes;
+        // window element e (= byte of the dword window) is channel (e-1)%3 of patch column (e-1)/3: inside the frame for e in [elo, ehi)
+        const int elo = 1 + 3 * max(0, -ix0), ehi = 1 + 3 * min(PR, W - ix0);
+        for (int d = tid; d < PR * ND; d += 256) {
+            const int pr = d / ND, dc = d - pr * ND;
+            const int iy = iy0 + pr, bx = bx0 + dc * 4;
+            const bool rin = (unsigned)iy < (unsigned)H;
+            unsigned v4 = 0u;
+            if (rin && bx >= 0 && bx + 4 <= rowbytes) v4 = *(const unsigned *)(base + (size_t)iy * rowbytes + bx);
+            sm_half4 h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = dc * 4 + j, v = (v4 >> (8 * j)) & 0xFF;
+                h[j] = (rin && e >= elo && e < ehi) ? (_Float16)(float)(2 * v - 255) : (_Float16)0.f;
+            }
+            *(sm_half4 *)(sIn + pr * RSH + dc * 4) = h;
+        }
+        __syncthreads();
+        char *sS = sSt + wave * (TS * OROWB);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int orow = wave * 4 + rr;                   // output row of the tile; lane = pixel frow of it
+            const int pbase = (orow * STRIDE) * RSH + 1 + frow * STRIDE * 3;
+            sm_half8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; j++) pf[j] = sIn[koff[j] >= 0 ? pbase + koff[j] : PR * RSH];
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+                sm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf, acc, 0, 0, 0);
+                sm_f32x4 v = acc + bv[ni];
+                if (act == ACT_RELU) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = fmaxf(v[i], 0.f);
+                } else if (act == ACT_PRELU) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = v[i] > 0.f ? v[i] : v[i] * sl[ni][i];
+                }
+                *(sm_half4 *)(sS + frow * OROWB + (ni * 16 + fq * 4) * 2) = __builtin_convertvector(v, sm_half4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int oy = ty * TS + orow;
+#pragma unroll
+            for (int g = lane; g < TS * CPP; g += 64) {
+                const int p = g / CPP, c = g - p * CPP;
+                const sm_u32x4 o = *(const sm_u32x4 *)(sS + p * OROWB + c * 16);
+                const int ox = tx * TS + p;
+                if (oy < Ho && ox < Wo) *(sm_u32x4 *)((char *)out + (((size_t)n * Ho + oy) * Wo + ox) * OROWB + c * 16) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging read back before the next row overwrites it
+        }
+        __syncthreads();                                      // everyone is done with the patch
+    }
+}
+
 // ---- max pool k x k / stride / pad on NHWC fp16, 8 channels (16 B) per thread ----------------------
 __global__ void __launch_bounds__(256) maxpool_nhwc(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int H, int W,
                                                     int Ho, int Wo, int Cp, int k, int stride, int pad, long long total) {
@@ -177,6 +286,18 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             const int cpw = dst.Cp / 4;
             const float *w = (const float *)(blob + op[W_WOFF]);
             dim3 grid((unsigned)cdiv64(total, 64));
+            static const bool valu = getenv("FID_STEM_VALU") != nullptr;   // the VALU kernel stays for comparison
+            const int st = op[W_STRIDE];
+            if (!valu && net->in_w % 4 == 0 && (st == 1 || st == 2) && (dst.Cp == 16 || dst.Cp == 32 || dst.Cp == 64)) {
+                const int tx = cdiv(dst.W, 16), ty = cdiv(dst.H, 16), nt = batch * tx * ty;
+                const int g = std::min(nt, ctx->num_cus * 4);
+#define STEMM(NI, ST) hipLaunchKernelGGL((stem_conv_mfma<NI, ST>), dim3(g), dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, op[W_ACT], tx, ty, nt)
+                if (dst.Cp == 64) { if (st == 1) STEMM(4, 1); else STEMM(4, 2); }
+                else if (dst.Cp == 32) { if (st == 1) STEMM(2, 1); else STEMM(2, 2); }
+                else { if (st == 1) STEMM(1, 1); else STEMM(1, 2); }
+#undef STEMM
+                break;
+            }
             static const int split = getenv("FID_STEM_SPLIT") ? atoi(getenv("FID_STEM_SPLIT")) : 2;   // measured on IResNet stem: 4 -> 107 us, 2 -> 91 us, 1 -> 102 us
 #define STEM(CPW) hipLaunchKernelGGL(stem_conv3x3<CPW>, grid, dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, dst.Cp, op[W_STRIDE], op[W_ACT], total)
 #define STEMS(CPW, SP) hipLaunchKernelGGL((stem_conv3x3<CPW, SP>), dim3((unsigned)cdiv64(total, 64 * (4 / SP))), dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, dst.Cp, op[W_STRIDE], op[W_ACT], total)
