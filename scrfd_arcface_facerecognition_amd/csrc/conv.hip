@@ -825,11 +825,14 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
     if (conv_pc_applicable(a)) {
         ConvPlan d{};
         d.gen = 5; d.ksplit = 1; d.bm = 256; d.bk = 32;
+        if (a.flags & CF_OUT_F32) { d.bn = 32; d.ns = 0; out.push_back(d); }
+        else {
         d.bn = 64; d.ns = 0; out.push_back(d);
         // weights two steps ahead instead of patches: measured equal or 1-2 % slower everywhere; kept for tests / experiments
         if (getenv("FID_FORCE_NS")) { d.ns = 1; out.push_back(d); }
         d.ns = 0;
         if (a.Cout_p % 96 == 0) { d.bn = 96; out.push_back(d); }
+        }
     }
     if (conv_pp_applicable(a)) {
         ConvPlan d{};

@@ -46,7 +46,7 @@ struct PCArgs {
     const void *res;
     void *out;
     int H, W, Cin_p, Cout_p;
-    int act, flags, res_Cp;
+    int act, flags, res_Cp, nsig;
     int tiles_x, tiles_per_img, n_cblk, n_items, n_chunks;
     FastDiv d_cblk, d_tpi, d_tx;
     unsigned in_bytes, w_bytes;
@@ -90,7 +90,9 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // NI: couts per consumer wave = NI*16 (workgroup CB = 2*NI*16).  WD / PD: ring depths of the weight / patch chunks; a stream
 // with depth 3 is fetched two steps ahead (its youngest chunk may still be in flight at the step's barrier), depth 2 one
 // step ahead.  CB = 96 only fits 2 + 2; CB = 64 fits 2 + 3 (patches, HBM, two ahead) or 3 + 2 (weights two ahead).
-template <int NI, int WD, int PD>
+// F32: the detector's 32-channel head convs -- fp32 outputs with a sigmoid on the first nsig channels; the consumers store
+// their accumulator rows directly (16 B = four fp32 couts per lane, 64 B per pixel and wave), no staging, no flush steps.
+template <int NI, int WD, int PD, bool F32 = false>
 __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PCArgs a) {
     constexpr int CB = 2 * NI * 16, MI = 4;
     constexpr int W_BLKS = 9 * CB * 64 / 1024, W_BYTES = W_BLKS * 1024;
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             STAMP(0, 1);
             raw_barrier();                                     // T(s)
             STAMP(0, 2);
-            const bool flush = ck == 0 && s > 0;               // the consumers write out the previous tile first
+            const bool flush = !F32 && ck == 0 && s > 0;       // the consumers write out the previous tile first
             const bool have_w = s + AW < n_steps, have_p = s + AP < n_steps;
             char *stage = sWr + ((s + WD - 1) % WD) * W_BYTES; // step s-1's weight slot = where W(s+AW) goes
             young = 0;
@@ -374,6 +376,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             STAMP(0, 4);
             if (++ck == a.n_chunks) { ck = 0; item += gridDim.x; }
         }
+        if (F32) return;                                       // (no staged tile to write out)
         raw_barrier();                                         // tail A: every consumer is done with the last weight slot
         if (has_res) {
             wait_vmcnt_n<0>();
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
 
     constexpr int OROWB = NI * 32, OCPP = NI * 2;
     constexpr int OMASK = (OCPP & (OCPP - 1)) == 0 ? OCPP - 1 : 0;
-    static_assert(N_CONS * 64 * OROWB <= W_BYTES, "staging must fit a weight slot");
+    static_assert(F32 || N_CONS * 64 * OROWB <= W_BYTES, "staging must fit a weight slot");
     EpiPix px[MI];
     int co0[NI];
     EpiRegs<NI, MI> R;
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         if (wave == 0 || wave == 7) STAMP(who, 0);
         raw_barrier();                                      // T(s): the producer saw W(s), P(s) land; everyone is done with step s-1
         if (wave == 0 || wave == 7) STAMP(who, 1);
-        if (ck == 0 && s > 0) {
+        if (!F32 && ck == 0 && s > 0) {
             char *slot = sWr + ((s + WD - 1) % WD) * W_BYTES;   // step s-1's weight slot
             if (has_res) {
                 raw_barrier();                              // R(s): the producers have put the residual tile there
@@ -478,7 +481,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         }
         if (wave == 0 || wave == 7) STAMP(who, 2);
         const bool last_chunk = ck == a.n_chunks - 1;
-        if (last_chunk) epi_prefetch(item);                // bias / slope / residual: they return during the matrix work
+        if (last_chunk && !F32) epi_prefetch(item);        // bias / slope / residual: they return during the matrix work
         if (wave == 0 || wave == 7) STAMP(who, 3);
         if (ck == 0) {
 #pragma unroll
@@ -520,10 +523,36 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             }
         }
         if (wave == 0 || wave == 7) STAMP(who, 4);
-        if (last_chunk && !has_res) epilogue_values_fast<NI, MI>(ep, acc, px, co0, R, hv);   // kept in registers until the next step stages them
+        if (F32) {
+            if (last_chunk) {                               // bias, sigmoid on the class scores, fp32 rows straight to memory
+                int n, ty, tx, cb;
+                decode_item(item, n, ty, tx, cb);
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const int frow = lo & 15, fq = lo >> 4;
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++) {
+                    const int co = cb * CB + (grp * NI + ni) * 16 + fq * 4;
+                    const f32x4 b = (a.bias != nullptr && co < a.Cout_p) ? *(const f32x4 *)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int mi = 0; mi < MI; mi++) {
+                        f32x4 v = acc[ni][mi] + b;
+                        if (co < a.nsig) {                  // (only the lanes that hold class scores)
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if (co + i < a.nsig) v[i] = 1.f / (1.f + expf(-v[i]));
+                        }
+                        const int oy = ty * TH + wg * MI + mi, ox = tx * TW + frow;
+                        if (oy < a.H && ox < a.W && co < a.Cout_p)
+                            *(f32x4 *)((float *)a.out + (((size_t)n * a.H + oy) * a.W + ox) * a.Cout_p + co) = v;
+                    }
+                }
+            }
+        } else if (last_chunk && !has_res) epilogue_values_fast<NI, MI>(ep, acc, px, co0, R, hv);   // kept in registers until the next step stages them
         if (wave == 0 || wave == 7) STAMP(who, 5);
         if (++ck == a.n_chunks) { ck = 0; li++; }
     }
+    if (F32) return;
     raw_barrier();                                          // tail A: all consumers are done reading the last weight slot
     if (has_res) {
         raw_barrier();                                      // tail R
@@ -533,16 +562,16 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
     raw_barrier();                                          // tail B: the producers store the last tile
 }
 
-template <int NI, int WD, int PD>
+template <int NI, int WD, int PD, bool F32 = false>
 int launch_pc(fid_ctx *ctx, const PCArgs &a) {
     constexpr size_t lds = (size_t)WD * 9 * 2 * NI * 16 * 64 + (size_t)PD * P_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pc<NI, WD, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pc<NI, WD, PD, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int grid = std::min(a.n_items, ctx->num_cus);
-    hipLaunchKernelGGL((conv3x3_pc<NI, WD, PD>), dim3(grid), dim3((N_CONS + N_PROD) * 64), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv3x3_pc<NI, WD, PD, F32>), dim3(grid), dim3((N_CONS + N_PROD) * 64), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());
 #ifdef FID_PC_STAMPS
     if (const char *e = getenv("FID_PC_STAMP_DUMP")) {
@@ -571,10 +600,12 @@ int launch_pc(fid_ctx *ctx, const PCArgs &a) {
 
 bool conv_pc_applicable(const ConvArgs &a) {
     if (getenv("FID_NO_PC")) return false;
-    return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Cin_p % 32 == 0 && a.Cin_p >= 64 && a.Cout_p >= 64 &&
-           a.w_rows == a.Cout_p && a.H == a.Ho && a.W == a.Wo && a.H >= 12 && a.W >= 12 &&
-           !(a.flags & (CF_RES_UP2 | CF_ARGMAX | CF_OUT_F32)) && a.nsig == 0 &&
-           (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo));
+    const bool shape = a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Cin_p % 32 == 0 && a.Cin_p >= 64 &&
+                       a.w_rows == a.Cout_p && a.H == a.Ho && a.W == a.Wo && a.H >= 12 && a.W >= 12 && !(a.flags & (CF_RES_UP2 | CF_ARGMAX));
+    if (!shape) return false;
+    if (a.flags & CF_OUT_F32)   // the detector head maps: 32 fp32 channels, no activation / residual / border classes
+        return a.Cout_p == 32 && a.act == ACT_NONE && a.res == nullptr && !(a.flags & CF_BORDER);
+    return a.Cout_p >= 64 && a.nsig == 0 && (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo));
 }
 
 // cb: output channels per work item (64 or 96); ring: 0 = patches two steps ahead (CB = 64) / both one ahead (CB = 96),
@@ -583,7 +614,7 @@ int conv_pc_launch(fid_ctx *ctx, const ConvArgs &c, int cb, int ring) {
     PCArgs a{};
     a.in = c.in; a.w = c.w; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
-    a.act = c.act; a.flags = c.flags; a.res_Cp = c.res_Cp;
+    a.act = c.act; a.flags = c.flags; a.res_Cp = c.res_Cp; a.nsig = c.nsig;
     const int B = c.M / (c.Ho * c.Wo);
     a.tiles_x = cdiv(c.W, TW);
     a.tiles_per_img = a.tiles_x * cdiv(c.H, TH);
@@ -595,6 +626,7 @@ int conv_pc_launch(fid_ctx *ctx, const ConvArgs &c, int cb, int ring) {
     a.w_bytes = (unsigned)std::min<size_t>(c.w_bytes, (size_t)c.w_rows * 9 * c.Cin_p * 2);   // rows past the bank read as 0
     if (const char *e = getenv("FID_PC_ABLATE")) a.ablate = atoi(e);
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
+    if (cb == 32) return launch_pc<1, 2, 3, true>(ctx, a);
     if (cb == 64 && ring == 1) return launch_pc<2, 3, 2>(ctx, a);
     if (cb == 64) return launch_pc<2, 2, 3>(ctx, a);
     if (cb == 96) return launch_pc<3, 2, 2>(ctx, a);

@@ -50,3 +50,27 @@ def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))[net.outputs[0]]
     ref = np.transpose(ref, (0, 2, 3, 1))
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3
+
+
+# the detector head maps (32 fp32 channels, sigmoid on the class scores) through every family that takes them
+@pytest.mark.parametrize("gen", [0, 1, 2, 5])
+@pytest.mark.parametrize("hw,cin,batch", [((96, 160), 80, 2), ((104, 104), 64, 3)])
+def test_dethead_family(ctx, monkeypatch, gen, hw, cin, batch):
+    from scrfd_arcface_facerecognition_amd.archs import DetHead
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    monkeypatch.setenv("FID_FORCE_GEN", str(gen))
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 64, stride=2, act="relu"))
+    net.add(Conv("t0", "s", 64, cin, stride=2, act="relu"))
+    net.add(DetHead("h", "t0", cin, 8))
+    net.outputs = ["h"]
+    P = archs.synth_params(net, seed=4)
+    images = np.random.default_rng(5).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    cn.run(images)
+    fused = cn.read("h", batch)                          # [B,H,W,30]: cls(2) bbox(8) kps(20)
+    cn.close()
+    sc, bb, kp = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["h"]
+    assert np.abs(fused[..., 0:2].reshape(batch, -1, 1) - sc).max() < 2e-3
+    assert np.abs(fused[..., 2:10].reshape(batch, -1, 4) - bb).max() < 2e-2
+    assert np.abs(fused[..., 10:30].reshape(batch, -1, 10) - kp).max() < 2e-2
