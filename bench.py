@@ -76,7 +76,7 @@ def build(ctx, batch, F, gallery_size, calib_frames):
 
 def mfma_roofline(pipe, frames_dev, batch, F):
     """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs."""
-    from scrfd_arcface_facerecognition_amd.lower import OP_CONV, OP_STEMFUSED
+    from scrfd_arcface_facerecognition_amd.lower import OP_CONV, OP_STEM, OP_STEMFUSED
     tot_ms, tot_flop, launches, per_net = 0.0, 0.0, 0, {}
     for name, cn, imgs, n in (("scrfd_10g", pipe.det, frames_dev, batch), ("arcface_r50", pipe.rec, pipe.crops, batch * F)):
         best = None
@@ -86,7 +86,7 @@ def mfma_roofline(pipe, frames_dev, batch, F):
         t, fl, k = 0.0, 0.0, 0
         by_name = {nd.name: nd for nd in cn.net.nodes}
         for oi, names in enumerate(cn.low.op_nodes):
-            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEMFUSED):
+            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED):
                 continue
             macs = sum(node_macs(cn.net, by_name[nm]) for nm in names)
             t += float(best[oi]); fl += 2.0 * macs * n; k += 1
@@ -103,7 +103,7 @@ def mfma_roofline(pipe, frames_dev, batch, F):
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
             "kernel": "MFMA conv kernels of one step: conv_mfma_kernel<*> / conv_mfma_dma_kernel<*> / conv3x3_direct<*> / "
-                      "conv3x3_chunked<*> / conv3x3_pc<*> / conv3x3_pcr / scrfd_stem_fused<*> (per layer the autotuner's pick)", "launches": launches,
+                      "conv3x3_chunked<*> / conv3x3_pc<*> / conv3x3_pcr / scrfd_stem_fused<*> / stem_conv_mfma<*> (per layer the autotuner's pick)", "launches": launches,
             "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2), "gflop_per_step": round(tot_flop / 1e9, 1),
             "per_net": per_net}
 

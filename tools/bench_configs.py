@@ -3,9 +3,10 @@
 
   cfg1  SCRFD-500M + MobileFaceNet, 1 frame 640x640, 5-entry gallery        (the reference's CPU-runnable case)
   cfg2  SCRFD-10G + IResNet-50, 64 frames, 1 k gallery, F = 8 faces per frame (bench.py quotes F = 1)
+  cfg4  IResNet-50 alone: 10 000 resident 112x112 crops in chunks of 500, each chunk matched against a 1 M gallery
   cfg5  SCRFD-2.5G + MobileFaceNet, 32 frames of 1080x1920 (one rank's share), letterboxed on the device, 1 k gallery
 
-Usage: python tools/bench_configs.py [cfg1|cfg2f8|cfg5 ...]     -> one JSON object per configuration
+Usage: python tools/bench_configs.py [cfg1|cfg2f8|cfg4|cfg5 ...]     -> one JSON object per configuration
 Synthetic frames and random-init weights (seed 0), frames resident in HBM before the timed region."""
 import json
 import os
@@ -27,7 +28,47 @@ CFG = {
 }
 
 
+def run_cfg4(n_crops=10_000, chunk=500, G=1_000_000):
+    """BASELINE.json configs[3]: no detector; embed + L2-normalise + match, crops and gallery resident in HBM."""
+    import ctypes as C
+    from scrfd_arcface_facerecognition_amd._lib import check
+    ctx = Context(0)
+    net = archs.ARCHS["arcface_r50"]()
+    rec = CompiledNet(ctx, net, archs.synth_params(net, 0), max_batch=chunk)
+    rng = np.random.default_rng(99)
+    gal_h = rng.standard_normal((G, 512), dtype=np.float32)
+    gal = Gallery(ctx, gal_h)
+    del gal_h
+    crops = ctx.to_device(np.random.default_rng(7).integers(0, 256, (n_crops, 112, 112, 3), dtype=np.uint8))
+    q = ctx.empty((chunk, 512), np.float16)
+    idx, sc = ctx.empty((n_crops,), np.int32), ctx.empty((n_crops,), np.float32)
+    emb_ptr, _, _ = rec.tensor(rec.low.outputs[0])
+    per = 112 * 112 * 3
+
+    def one_pass():
+        for first in range(0, n_crops, chunk):
+            nb = min(chunk, n_crops - first)
+            check(ctx.lib.fid_net_run(ctx.handle, rec.handle, C.c_void_p(crops.ptr + first * per), nb))
+            check(ctx.lib.fid_l2_normalize_f16(ctx.handle, C.c_void_p(emb_ptr), nb, 512, C.c_void_p(q.ptr)))
+            check(ctx.lib.fid_match(ctx.handle, gal.handle, C.c_void_p(q.ptr), nb, C.c_float(0.4),
+                                    C.c_void_p(idx.ptr + first * 4), C.c_void_p(sc.ptr + first * 4)))
+
+    one_pass()
+    ctx.sync()
+    t0 = time.perf_counter()
+    one_pass()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    gflop_face = 2.0 * rec.macs_per_image() / 1e9
+    print(json.dumps({"config": "cfg4", "rec": "arcface_r50", "crops": n_crops, "chunk": chunk, "gallery": G,
+                      "s_per_pass": round(dt, 4), "faces_per_s": round(n_crops / dt, 1),
+                      "embed_gflop_per_face": round(gflop_face, 2), "match_gflop_per_face": round(2.0 * 512 * G / 1e9, 3),
+                      "tflops_embed_plus_match": round(n_crops * (gflop_face + 2.0 * 512 * G / 1e9) / dt / 1e3, 1)}), flush=True)
+
+
 def run(name):
+    if name == "cfg4":
+        return run_cfg4()
     c = CFG[name]
     ctx = Context(0)
     det_net = archs.ARCHS[c["det"]]()
@@ -57,5 +98,5 @@ def run(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CFG)):
+    for n in (sys.argv[1:] or list(CFG) + ["cfg4"]):
         run(n)
