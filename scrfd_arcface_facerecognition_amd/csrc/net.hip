@@ -25,6 +25,11 @@ struct fid_net {
     size_t partial_cap = 0;
     hipEvent_t *prof_events = nullptr;
     int n_prof_events = 0;
+    // hipGraph replay of the launch sequence: one executable graph per (frame buffer, batch) the caller keeps coming back with
+    struct Replay { hipGraphExec_t exec = nullptr; int seen = 0; unsigned long long last_use = 0; const void *partial = nullptr; };
+    std::map<std::pair<const void *, int>, Replay> replays;
+    unsigned long long run_counter = 0;
+    int graphs = 0;      // FID_GRAPH=1 turns the replay on (measured: no gain on this stack)
 };
 
 namespace fid {
@@ -462,9 +467,59 @@ int run_all(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float 
         // depth-first over sub-batches: every layer's input was written a moment ago by the previous
         // layer of the SAME sub-batch and is still in L2 / Infinity Cache instead of coming back from HBM
         const int sb = net->sub_batch > 0 ? net->sub_batch : batch;
-        for (int first = 0; first < batch; first += sb) {
-            const int nb = std::min(sb, batch - first);
-            for (int oi = 0; oi < net->n_ops; oi++) FID_TRY(run_op(ctx, net, oi, images, first, nb, need ? partial_ws : nullptr));
+        auto issue = [&]() -> int {
+            for (int first = 0; first < batch; first += sb) {
+                const int nb = std::min(sb, batch - first);
+                for (int oi = 0; oi < net->n_ops; oi++) FID_TRY(run_op(ctx, net, oi, images, first, nb, need ? partial_ws : nullptr));
+            }
+            return FID_OK;
+        };
+        // The sequence is fixed once every op has its tuned plan, so a caller that comes back with the same frame buffer and
+        // batch (the pipeline's resident buffers) gets ONE graph launch instead of n_ops kernel launches.  The first two runs
+        // of a key are issued eagerly (the autotuner synchronises, launchers set function attributes, scratch may grow: none
+        // of that may happen inside a capture); at most MAX_REPLAYS graphs are kept, least recently used first out.
+        constexpr int MAX_REPLAYS = 8;
+        net->run_counter++;
+        fid_net::Replay *rp = nullptr;
+        if (net->graphs) {
+            auto key = std::make_pair((const void *)images, batch);
+            auto it = net->replays.find(key);
+            if (it == net->replays.end()) {
+                if ((int)net->replays.size() >= MAX_REPLAYS) {
+                    auto victim = net->replays.begin();
+                    for (auto j = net->replays.begin(); j != net->replays.end(); ++j)
+                        if (j->second.last_use < victim->second.last_use) victim = j;
+                    if (victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
+                    net->replays.erase(victim);
+                }
+                it = net->replays.emplace(key, fid_net::Replay{}).first;
+            }
+            rp = &it->second;
+            rp->last_use = net->run_counter;
+            rp->seen++;
+            if (rp->exec && rp->partial != partial_ws) {      // the context's split-K scratch was re-allocated (another net grew it)
+                (void)hipGraphExecDestroy(rp->exec);
+                rp->exec = nullptr;
+            }
+        }
+        if (rp && rp->exec) {
+            FID_HIP(hipGraphLaunch(rp->exec, ctx->stream));
+        } else if (rp && rp->seen > 2) {
+            hipGraph_t g = nullptr;
+            FID_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+            const int rc = issue();
+            const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+            if (rc != FID_OK) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc;
+            }
+            FID_HIP(ce);
+            FID_HIP(hipGraphInstantiate(&rp->exec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            rp->partial = partial_ws;
+            FID_HIP(hipGraphLaunch(rp->exec, ctx->stream));
+        } else {
+            FID_TRY(issue());
         }
     }
     FID_HIP(hipGetLastError());
@@ -539,6 +594,7 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
     FID_HIP(hipMemcpy(net->blob, blob, blob_bytes, hipMemcpyHostToDevice));
     if (const char *e = getenv("FID_SUB_BATCH")) net->sub_batch = atoi(e);
     if (const char *e = getenv("FID_AUTOTUNE")) net->autotune = atoi(e);
+    if (const char *e = getenv("FID_GRAPH")) net->graphs = atoi(e);
     net->tuned.resize(n_ops);
     *out = net;
     return FID_OK;
@@ -547,6 +603,9 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
 int fid_net_set_sub_batch(fid_net *net, int sub_batch) {
     FID_REQUIRE(net && sub_batch >= 0, "bad args");
     net->sub_batch = sub_batch;
+    for (auto &kv : net->replays)      // recorded launch sequences no longer match
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    net->replays.clear();
     return FID_OK;
 }
 
@@ -556,6 +615,8 @@ int fid_net_destroy(fid_ctx *ctx, fid_net *net) {
     for (void *p : net->slots)
         if (p) (void)hipFree(p);
     if (net->blob) (void)hipFree(net->blob);
+    for (auto &kv : net->replays)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     if (net->prof_events) {
         for (int i = 0; i < net->n_prof_events; i++) (void)hipEventDestroy(net->prof_events[i]);
         delete[] net->prof_events;
