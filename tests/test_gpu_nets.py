@@ -148,3 +148,40 @@ def test_scrfd_heads(ctx, arch):
         assert np.abs(fused[..., 2:10].reshape(1, -1, 4) - bb).max() < 3e-2, name      # stride units
         assert np.abs(fused[..., 10:30].reshape(1, -1, 10) - kp).max() < 3e-2, name
     cn.close()
+
+
+def test_graph_replay_matches_eager(ctx, monkeypatch):
+    """FID_GRAPH=1: from the third run on the same frame buffer the launch sequence is replayed as one hipGraph;
+    results must be bit-identical to the eager runs, also after new frames are copied into the buffer and after
+    another net made the context's split-K scratch grow."""
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    monkeypatch.setenv("FID_GRAPH", "1")
+    monkeypatch.setenv("FID_AUTOTUNE", "0")               # both nets below on the same (heuristic) plans -> same summation order
+    net = archs.scrfd_500m((160, 160))
+    P = archs.synth_params(net, seed=3)
+    rng = np.random.default_rng(8)
+    a, b = (rng.integers(0, 256, (2, 160, 160, 3), dtype=np.uint8) for _ in range(2))
+    cn = CompiledNet(ctx, net, P, max_batch=2)
+    buf = ctx.to_device(a)
+    outs = []
+    for i in range(5):
+        cn.run_device(buf, 2)
+        outs.append([cn.read(k, 2).copy() for k in net.outputs])
+    for o in outs[1:]:
+        for x, y in zip(o, outs[0]):
+            assert np.array_equal(x, y)
+    buf.upload(b)
+    cn.run_device(buf, 2)                                  # replayed graph, new pixels in the same buffer
+    got_b = [cn.read(k, 2).copy() for k in net.outputs]
+    monkeypatch.setenv("FID_GRAPH", "0")
+    eager = CompiledNet(ctx, net, P, max_batch=2)
+    eager.run_device(buf, 2)
+    for k, x in zip(net.outputs, got_b):
+        assert np.array_equal(x, eager.read(k, 2))
+    big = archs.iresnet50()
+    other = CompiledNet(ctx, big, archs.synth_params(big, seed=1), max_batch=4)      # grows the shared scratch
+    other.run(rng.integers(0, 256, (4, 112, 112, 3), dtype=np.uint8))
+    cn.run_device(buf, 2)
+    for k, x in zip(net.outputs, got_b):
+        assert np.array_equal(x, cn.read(k, 2))
+    other.close(); eager.close(); cn.close()
