@@ -60,6 +60,14 @@ inline FastDiv fastdiv_make(int d) {
     return f;
 }
 #ifdef __HIPCC__
+// Workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2): position of workgroup b in XCD-major order, so
+// that workgroups which share an L2 get CONSECUTIVE work items (neighbouring tiles share halo pixels, the cout blocks of one
+// tile share its whole patch).  A bijection on [0, g); speed only, never correctness.
+__device__ __forceinline__ int xcd_major_id(int b, int g) {
+    const int q = g >> 3, r = g & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 __device__ __forceinline__ int fastdiv(int x, const FastDiv &f) { return f.d == 1 ? x : (int)(__umulhi((unsigned)x, f.mul) >> f.shr); }
 #endif
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -50,7 +50,7 @@ struct PCArgs {
     int tiles_x, tiles_per_img, n_cblk, n_items, n_chunks;
     FastDiv d_cblk, d_tpi, d_tx;
     unsigned in_bytes, w_bytes;
-    int ablate;   // timing experiments only (FID_PC_ABLATE: 1 = no weight DMA, 2 = no patch DMA)
+    int ablate;   // timing experiments only (FID_PC_ABLATE: 1 = no weight DMA, 2 = no patch DMA, 4 = weight DMA from chunk-contiguous addresses, 8 = every patch from image 0, 16 = interior-tile addressing everywhere)
 };
 
 // Diagnostic build only (make EXTRA=-DFID_PC_STAMPS): s_memtime stamps of workgroup 0 -- producer, consumer waves 0 and 7.
@@ -92,7 +92,10 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // step ahead.  CB = 96 only fits 2 + 2; CB = 64 fits 2 + 3 (patches, HBM, two ahead) or 3 + 2 (weights two ahead).
 // F32: the detector's 32-channel head convs -- fp32 outputs with a sigmoid on the first nsig channels; the consumers store
 // their accumulator rows directly (16 B = four fp32 couts per lane, 64 B per pixel and wave), no staging, no flush steps.
-template <int NI, int WD, int PD, bool F32 = false>
+// RS (opt-in, FID_PC_RS=1): the producers fetch with plain buffer loads into registers and write the LDS rings themselves
+// within the step, instead of LDS-DMA.  Built to test whether the DMA issue rate (stamped: ~76 cycles per 1-KB piece per CU
+// however many waves issue them) bounds a step; it does not -- the loads' own return time is as long.
+template <int NI, int WD, int PD, bool F32 = false, bool RS = false>
 __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PCArgs a) {
     constexpr int CB = 2 * NI * 16, MI = 4;
     constexpr int W_BLKS = 9 * CB * 64 / 1024, W_BYTES = W_BLKS * 1024;
@@ -102,8 +105,10 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
     char *sWr = smem, *sPr = smem + WD * W_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // my items: blockIdx.x, + gridDim.x, ...; steps = (local item, chunk) linearised
-    const int my_items = blockIdx.x < a.n_items ? (a.n_items - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    // my items: bid, + gridDim.x, ...; steps = (local item, chunk) linearised.  bid = my place in XCD-major order: the
+    // workgroups of one XCD work on consecutive items (the cout blocks of a tile, then the next tile of the row)
+    const int bid = (a.ablate & 256) ? (int)blockIdx.x : xcd_major_id(blockIdx.x, gridDim.x);
+    const int my_items = bid < a.n_items ? (a.n_items - 1 - bid) / gridDim.x + 1 : 0;
     const int n_steps = my_items * a.n_chunks;
     if (n_steps == 0) return;
 
@@ -120,6 +125,8 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         // four of them: one wave issues an LDS-DMA only every ~75 cycles (stamped: 5700 cycles for the 75 blocks of a step),
         // the address path takes one per 16; producer pw owns blocks pw, pw+4, ... of every weight and patch chunk
         const int pw = wave - N_CONS;
+        __builtin_assume(pw >= 0 && pw < N_PROD);
+        if (a.ablate & 512) __builtin_amdgcn_s_setprio(3);   // experiment: the producers' few instructions ahead of the consumers' MFMA streams
         constexpr int MAX_W = (W_BLKS + N_PROD - 1) / N_PROD, MAX_P = (P_BLKS + N_PROD - 1) / N_PROD;
         const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
         const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
@@ -132,10 +139,11 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             const int row = j * 16 + (lane >> 2);
             const int t = row / CB, co = row - t * CB;
             w_off[k] = ((co * 9 + t) * a.Cin_p + ((lane & 3) ^ swz64(row)) * 8) * 2;
+            if (a.ablate & 4) w_off[k] = j * 1024 + lane * 16;   // timing experiment: chunk-contiguous weights (wrong results)
         }
         // py | px << 8 | channel offset << 16 (py = 255: padding row) of my k-th patch block; recomputed where needed (border
         // tiles only) instead of held in registers: the producers' register budget goes to the tile they carry
-        constexpr bool KEEP_PK = NI <= 2;                   // CB = 64 has the registers to keep them (small maps are all border tiles)
+        constexpr bool KEEP_PK = NI <= 2 && !RS;                   // CB = 64 has the registers to keep them (small maps are all border tiles)
         auto patch_pk_calc = [&](int k) {
             int lo = lane;
             asm volatile("" : "+v"(lo));
@@ -162,9 +170,9 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         // issue with the consumers' epilogue arithmetic: stamped, address arithmetic tripled the steps that have one)
         int p_off[MAX_P];
 #pragma unroll
-        for (int k = 0; k < MAX_P; k++) {
+        for (int k = 0; k < (RS ? 0 : MAX_P); k++) {
             const int pk = patch_pk(k), py = pk & 255, px = (pk >> 8) & 255;
-            p_off[k] = py == 255 ? -1 : ((py * a.W + px) * a.Cin_p + (pk >> 16)) * 2;
+            p_off[k] = py == 255 ? -1 : ((py * a.W + px) * (a.Cin_p + ((a.ablate & 32) ? 32 : 0) + ((a.ablate & 64) ? 64 : 0)) + (pk >> 16)) * 2;   // (32 / 64: timing experiments, pixel pitch + 64 / 128 B)
         }
         // output stores: the consumers stage a finished fp16 tile in the accumulator layout's transpose (wave-major,
         // [64 pixels][NI*32 B], 16-byte chunks swizzled by pixel); the producers read it back as whole 16-byte cout segments and
@@ -267,7 +275,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             int n, ty, tx, cb;
             decode_item(c.item, n, ty, tx, cb);
             c.w_base = cb * CB * 9 * a.Cin_p * 2;
-            c.n = n; c.y0 = ty * TH - 1; c.x0 = tx * TW - 1;
+            c.n = (a.ablate & 8) ? 0 : n; c.y0 = ty * TH - 1; c.x0 = tx * TW - 1;   // (8: timing experiment, every patch from image 0)
         };
         auto cursor_next = [&](Cursor &c) {
             if (++c.ck == a.n_chunks) {
@@ -278,7 +286,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
         };
         auto issue_weights = [&](const Cursor &c, int slot) {
             if (a.ablate & 1) return;
-            const int ubase = c.w_base + c.ck * CK * 2;
+            const int ubase = (a.ablate & 4) ? c.ck * W_BYTES : c.w_base + c.ck * CK * 2;
             char *dst = sWr + slot * W_BYTES;
 #pragma unroll
             for (int k = 0; k < MAX_W; k++) {
@@ -292,7 +300,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             if (a.ablate & 2) return;
             const int c0 = c.ck * CK;
             char *dst = sPr + slot * P_BYTES;
-            if (c.y0 >= 0 && c.x0 >= 0 && c.y0 + TH + 2 <= a.H && c.x0 + TW + 2 <= a.W) {   // interior tile
+            if ((a.ablate & 16) || (c.y0 >= 0 && c.x0 >= 0 && c.y0 + TH + 2 <= a.H && c.x0 + TW + 2 <= a.W)) {   // interior tile (16: timing experiment)
                 const int base = (((c.n * a.H + c.y0) * a.W + c.x0) * a.Cin_p + c0) * 2;
 #pragma unroll
                 for (int k = 0; k < MAX_P; k++) {
@@ -315,12 +323,106 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             }
         };
 
+        // ---- register-staged variants of the two fetches (RS): load now, write the LDS image a step later ----
+        u32x4 wreg[RS ? MAX_W : 1], preg[RS ? MAX_P : 1];
+        auto load_weights = [&](const Cursor &c) {
+            if (a.ablate & 1) return;
+            const int ubase = c.w_base + c.ck * CK * 2;
+#pragma unroll
+            for (int k = 0; k < MAX_W; k++)
+                if (pw + N_PROD * k < W_BLKS) wreg[RS ? k : 0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(w_off[k] + ubase), 0, 0);
+        };
+        auto load_patch = [&](const Cursor &c) {
+            if (a.ablate & 2) return;
+            const int c0 = c.ck * CK;
+            if (c.y0 >= 0 && c.x0 >= 0 && c.y0 + TH + 2 <= a.H && c.x0 + TW + 2 <= a.W) {   // interior tile
+                const int base = (((c.n * a.H + c.y0) * a.W + c.x0) * a.Cin_p + c0) * 2;
+#pragma unroll
+                for (int k = 0; k < MAX_P; k++) {
+                    if (pw + N_PROD * k >= P_BLKS) continue;
+                    const int pk = patch_pk(k), py = pk & 255;   // (a register load is cheap to issue: no per-block offset table)
+                    const unsigned vo = py == 255 ? OOB : (unsigned)(((py * a.W + ((pk >> 8) & 255)) * a.Cin_p + (pk >> 16)) * 2 + base);
+                    preg[RS ? k : 0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0);
+                }
+                return;
+            }
+#pragma unroll
+            for (int k = 0; k < MAX_P; k++) {
+                if (pw + N_PROD * k >= P_BLKS) continue;
+                const int pk = patch_pk(k);
+                const int py = pk & 255, iy = c.y0 + py, ix = c.x0 + ((pk >> 8) & 255);
+                const bool in = py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned vo = in ? (unsigned)((((c.n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
+                preg[RS ? k : 0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, 0, 0);
+            }
+        };
+        auto commit_weights = [&](int slot) {                   // (the compiler waits for the loads where the registers are read)
+            char *dst = sWr + slot * W_BYTES + lane * 16;
+#pragma unroll
+            for (int k = 0; k < MAX_W; k++)
+                if (pw + N_PROD * k < W_BLKS) *(u32x4 *)(dst + (pw + N_PROD * k) * 1024) = wreg[RS ? k : 0];
+        };
+        auto commit_patch = [&](int slot) {
+            char *dst = sPr + slot * P_BYTES + lane * 16;
+#pragma unroll
+            for (int k = 0; k < MAX_P; k++)
+                if (pw + N_PROD * k < P_BLKS) *(u32x4 *)(dst + (pw + N_PROD * k) * 1024) = preg[RS ? k : 0];
+        };
+        auto lds_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
         const int my_w = (W_BLKS - pw + N_PROD - 1) / N_PROD;   // weight DMAs I issue per chunk
         // prologue: everything step 0 reads, then the two-ahead stream's chunk of step 1
         Cursor cw, cp;
-        cw.item = blockIdx.x; cw.ck = 0;
+        cw.item = bid; cw.ck = 0;
         cursor_decode(cw);
         cp = cw;
+        if constexpr (RS) {
+            // Step s (after its barrier T(s), which frees the slots step s-1 read): load W(s+AW) and P(s+AP) into registers
+            // while the consumers multiply, write them into their ring slots when they arrive, and finish the LDS writes before
+            // T(s+1).  The registers live inside one step; a cursor always stands on the next chunk its stream fetches.
+            auto fetch = [&](bool w, int wslot, bool p_, int pslot) {
+                if (p_) { load_patch(cp); cursor_next(cp); }
+                if (w) { load_weights(cw); cursor_next(cw); }
+                if (w) commit_weights(wslot);                  // (from L2: back first)
+                if (p_) commit_patch(pslot);
+            };
+            fetch(true, 0, true, 0);
+            if (n_steps > 1) fetch(AW == 2, 1, AP == 2, 1);
+            lds_done();
+            int ck = 0, item = bid;                     // chunk / item of the step the consumers are in
+            for (int s = 0; s < n_steps; s++) {
+                STAMP(0, 0);
+                STAMP(0, 1);
+                raw_barrier();                                 // T(s)
+                STAMP(0, 2);
+                if (!F32 && ck == 0 && s > 0) {                // the consumers write out the previous tile first
+                    char *stage = sWr + ((s + WD - 1) % WD) * W_BYTES;   // step s-1's weight slot = where W(s+AW) goes
+                    if (has_res) {                             // (loaded at the end of the step before)
+                        write_residual(stage);
+                        raw_barrier();                         // R(s): the consumers pick their residual values up
+                    }
+                    raw_barrier();                             // F(s): the previous tile is staged in the weight slot
+                    read_tile(stage);
+                    store_tile(item - gridDim.x);
+                }
+                STAMP(0, 3);
+                fetch(s + AW < n_steps, (s + AW) % WD, s + AP < n_steps, (s + AP) % PD);
+                if (has_res && ck == a.n_chunks - 1) load_residual(item);   // the item's last chunk: its residual tile
+                lds_done();
+                STAMP(0, 4);
+                if (++ck == a.n_chunks) { ck = 0; item += gridDim.x; }
+            }
+            if (F32) return;
+            raw_barrier();                                     // tail A: every consumer is done with the last weight slot
+            if (has_res) {
+                write_residual(sWr + ((n_steps - 1) % WD) * W_BYTES);
+                raw_barrier();                                 // tail R
+            }
+            raw_barrier();                                     // tail B: the last tile is staged
+            read_tile(sWr + ((n_steps - 1) % WD) * W_BYTES);
+            store_tile(item - gridDim.x);
+            return;
+        }
         issue_weights(cw, 0);
         issue_patch(cp, 0);
         cursor_next(cw);                                       // -> step 1
@@ -330,7 +432,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
             if (AP == 2) { issue_patch(cp, 1); cursor_next(cp); young = my_p; }
             if (AW == 2) { issue_weights(cw, 1); cursor_next(cw); young = my_w; }
         }
-        int ck = 0, item = blockIdx.x;                         // chunk / item of the step the consumers are in
+        int ck = 0, item = bid;                         // chunk / item of the step the consumers are in
         for (int s = 0; s < n_steps; s++) {
             // everything step s reads must have landed: W(s) and P(s); only `young` younger operations may stay in flight
             STAMP(0, 0);
@@ -465,7 +567,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
 
     int li = 0, ck = 0;                                   // local item index / chunk of the current step
     for (int s = 0; s < n_steps; s++) {
-        const int item = blockIdx.x + li * gridDim.x;
+        const int item = bid + li * gridDim.x;
         [[maybe_unused]] const int who = wave == 0 ? 1 : 2;
         if (wave == 0 || wave == 7) STAMP(who, 0);
         raw_barrier();                                      // T(s): the producer saw W(s), P(s) land; everyone is done with step s-1
@@ -562,16 +664,16 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
     raw_barrier();                                          // tail B: the producers store the last tile
 }
 
-template <int NI, int WD, int PD, bool F32 = false>
+template <int NI, int WD, int PD, bool F32 = false, bool RS = false>
 int launch_pc(fid_ctx *ctx, const PCArgs &a) {
     constexpr size_t lds = (size_t)WD * 9 * 2 * NI * 16 * 64 + (size_t)PD * P_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pc<NI, WD, PD, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pc<NI, WD, PD, F32, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int grid = std::min(a.n_items, ctx->num_cus);
-    hipLaunchKernelGGL((conv3x3_pc<NI, WD, PD, F32>), dim3(grid), dim3((N_CONS + N_PROD) * 64), lds, ctx->stream, a);
+    hipLaunchKernelGGL((conv3x3_pc<NI, WD, PD, F32, RS>), dim3(grid), dim3((N_CONS + N_PROD) * 64), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());
 #ifdef FID_PC_STAMPS
     if (const char *e = getenv("FID_PC_STAMP_DUMP")) {
@@ -626,9 +728,11 @@ int conv_pc_launch(fid_ctx *ctx, const ConvArgs &c, int cb, int ring) {
     a.w_bytes = (unsigned)std::min<size_t>(c.w_bytes, (size_t)c.w_rows * 9 * c.Cin_p * 2);   // rows past the bank read as 0
     if (const char *e = getenv("FID_PC_ABLATE")) a.ablate = atoi(e);
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
-    if (cb == 32) return launch_pc<1, 2, 3, true>(ctx, a);
+    // register-staged producers (FID_PC_RS=1) were measured 5-10 % slower than the LDS-DMA ones on every layer
+    const bool dma = getenv("FID_PC_RS") == nullptr;
+    if (cb == 32) return dma ? launch_pc<1, 2, 3, true>(ctx, a) : launch_pc<1, 2, 3, true, true>(ctx, a);
     if (cb == 64 && ring == 1) return launch_pc<2, 3, 2>(ctx, a);
-    if (cb == 64) return launch_pc<2, 2, 3>(ctx, a);
+    if (cb == 64) return dma ? launch_pc<2, 2, 3>(ctx, a) : launch_pc<2, 2, 3, false, true>(ctx, a);
     if (cb == 96) return launch_pc<3, 2, 2>(ctx, a);
     set_error("producer/consumer conv: cb=%d unsupported", cb);
     return FID_E_INVALID;
