@@ -116,10 +116,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
         c.w_base = cb * CB * 9 * a.Cin_p * 2;
         c.n = n; c.y0 = ty * TH - 1; c.x0 = tx * TW - 1;
     };
+    const int bid = xcd_major_id(blockIdx.x, gridDim.x);   // XCD-major item order: consecutive items in one L2 (halo overlap, cout blocks of a tile)
     auto cursor_init = [&](Cursor &c, int step) {          // position on step `step` of this workgroup (prologue only)
         const int li = step / a.n_chunks;
         c.ck = step - li * a.n_chunks;
-        c.item = blockIdx.x + li * gridDim.x;
+        c.item = bid + li * gridDim.x;
         cursor_decode(c);
     };
     auto cursor_next = [&](Cursor &c) {
@@ -153,8 +154,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
         }
     };
 
-    // my items: blockIdx.x, + gridDim.x, ...; steps = (local item, chunk) linearised
-    const int my_items = blockIdx.x < a.n_items ? (a.n_items - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    // my items: bid, + gridDim.x, ...; steps = (local item, chunk) linearised
+    const int my_items = bid < a.n_items ? (a.n_items - 1 - bid) / gridDim.x + 1 : 0;
     const int n_steps = my_items * a.n_chunks;
     const int frow = lane & 15, fq = lane >> 4;
     const int lin0 = (wg * MI) * PW + frow;
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_chunked(const ChunkArgs a) {
     f32x4 acc[NI][MI];
     int li = 0, ck = 0;                                   // local item index / chunk of the current step
     for (int s = 0; s < n_steps; s++) {
-        const int item = blockIdx.x + li * gridDim.x;
+        const int item = bid + li * gridDim.x;
         // outstanding, oldest first: [W(s), P(s) | P(s+1)] at s = 0, else [stores | W(s) | P(s+1)] (P(s) was issued a step
         // earlier, before W(s)); everything up to W(s) must have landed, only the newest patch may stay in flight
         if (AHEAD == 2 && s + 1 < n_steps) wait_vmcnt_c<MAX_P>();

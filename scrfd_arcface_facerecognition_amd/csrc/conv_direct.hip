@@ -140,8 +140,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_direct(const DirectArgs a) {
 
     // pair q of this workgroup = tiles (2q, 2q+1): group 0 takes the even one, group 1 the odd one
     const int n_pairs = (a.n_tiles + 1) >> 1;
-    const int my_pairs = blockIdx.x < n_pairs ? (n_pairs - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-    auto tile_of = [&](int i) { return (blockIdx.x + i * gridDim.x) * 2 + grp; };
+    const int bid = xcd_major_id(blockIdx.x, gridDim.x);   // XCD-major order: consecutive tile pairs (overlapping halos) in one L2
+    const int my_pairs = bid < n_pairs ? (n_pairs - 1 - bid) / gridDim.x + 1 : 0;
+    auto tile_of = [&](int i) { return (bid + i * gridDim.x) * 2 + grp; };
 
     if (my_pairs > 0 && tile_of(0) < a.n_tiles) fetch_patch(tile_of(0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -53,6 +53,7 @@ struct PCRArgs {
     int tiles_x, tiles_per_img, n_tiles;
     FastDiv d_tpi, d_tx;
     unsigned in_bytes, w_bytes;
+    int plain_order;   // experiment (FID_PCR_PLAIN_ORDER): tiles in workgroup-id order instead of XCD-major order
 };
 
 __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pcr(const PCRArgs a) {
@@ -60,7 +61,9 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pcr(const P
     char *sWr = smem, *sTr = smem + NCH * W_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int my_tiles = blockIdx.x < a.n_tiles ? (a.n_tiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    // bid = my place in XCD-major order: the workgroups of one XCD work on consecutive tiles (their halos overlap in that L2)
+    const int bid = a.plain_order ? (int)blockIdx.x : xcd_major_id(blockIdx.x, gridDim.x);
+    const int my_tiles = bid < a.n_tiles ? (a.n_tiles - 1 - bid) / gridDim.x + 1 : 0;
     if (my_tiles == 0) return;
     auto decode_tile = [&](int tile, int &n, int &ty, int &tx) {
         n = fastdiv(tile, a.d_tpi);
@@ -183,11 +186,11 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pcr(const P
         };
 
         // prologue: (weights issued above) patches of my first two tiles
-        issue_patch(blockIdx.x, 0);
-        if (my_tiles > 1) issue_patch(blockIdx.x + gridDim.x, 1);
-        if (has_res) move_tile(blockIdx.x, a.res, true);
+        issue_patch(bid, 0);
+        if (my_tiles > 1) issue_patch(bid + gridDim.x, 1);
+        if (has_res) move_tile(bid, a.res, true);
         bool stores_young = false;                              // the youngest MAX_S memory operations are output stores
-        int tile = blockIdx.x;                                  // the tile the consumers multiply in iteration t
+        int tile = bid;                                         // the tile the consumers multiply in iteration t
         for (int t = 0; t < my_tiles; t++) {
             // the patch of tile t (and at t = 0 the weights) and my residual segments must have landed; stores may fly on
             if (stores_young) wait_vmcnt_n<MAX_S>();
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pcr(const P
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged before the barrier that hands the slot to the producers
     };
 
-    int tile = blockIdx.x;
+    int tile = bid;
     for (int t = 0; t < my_tiles; t++) {
         raw_barrier();                                      // T(t): patch of tile t landed; everyone is done with tile t-1's slot
         if (t > 0) {
@@ -361,6 +364,7 @@ int conv_pcr_launch(fid_ctx *ctx, const ConvArgs &c) {
     a.n_tiles = B * a.tiles_per_img;
     a.d_tpi = fastdiv_make(a.tiles_per_img); a.d_tx = fastdiv_make(a.tiles_x);
     a.in_bytes = c.in_bytes;
+    a.plain_order = getenv("FID_PCR_PLAIN_ORDER") != nullptr;
     a.w_bytes = (unsigned)std::min<size_t>(c.w_bytes, (size_t)64 * 9 * 64 * 2);
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
     constexpr size_t lds = NCH * (size_t)W_BYTES + 2 * (size_t)T_BYTES;
