@@ -34,7 +34,7 @@ struct ConvArgs {
 // must hold ksplit*M*Cout_p floats when the plan splits K (query with conv_plan first).
 struct ConvPlan {
     int bm, bn, bk, ksplit;
-    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr
+    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr, 8 = conv_pc2
     int ns;    // ring slots (gen 2); 5 = 4 slots + fragment prefetch across K-steps
     size_t partial_bytes;
 };
@@ -62,6 +62,9 @@ bool conv_pc_applicable(const ConvArgs &a);
 int conv_pc_launch(fid_ctx *ctx, const ConvArgs &a, int cb, int ring);
 
 // conv_pcr.hip: 64 -> 64 channels, weights resident in LDS, 8 MFMA waves on one tile + 4 producer waves
+// two tiles per fetched weight chunk (generation 8, conv_pc2.hip): 64-cout blocks, Cout_p a multiple of 64
+bool conv_pc2_applicable(const ConvArgs &a);
+int conv_pc2_launch(fid_ctx *ctx, const ConvArgs &a);
 bool conv_pcr_applicable(const ConvArgs &a);
 int conv_pcr_launch(fid_ctx *ctx, const ConvArgs &a);
 

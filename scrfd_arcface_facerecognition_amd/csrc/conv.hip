@@ -822,6 +822,7 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
         if (a.Cout_p % 96 == 0) { d.bn = 96; out.push_back(d); }
     }
     if (conv_pcr_applicable(a)) { ConvPlan d{}; d.gen = 7; d.ksplit = 1; d.bm = 256; d.bn = 64; d.bk = 32; out.push_back(d); }
+    if (conv_pc2_applicable(a)) { ConvPlan d{}; d.gen = 8; d.ksplit = 1; d.bm = 512; d.bn = 64; d.bk = 32; out.push_back(d); }
     if (conv_pc_applicable(a)) {
         ConvPlan d{};
         d.gen = 5; d.ksplit = 1; d.bm = 256; d.bk = 32;
@@ -890,6 +891,7 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 4) return conv_pp_launch(ctx, a, plan.bn);
     if (plan.gen == 5) return conv_pc_launch(ctx, a, plan.bn, plan.ns);
     if (plan.gen == 7) return conv_pcr_launch(ctx, a);
+    if (plan.gen == 8) return conv_pc2_launch(ctx, a);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);
     FID_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 4 == 0, "conv: channel padding (Cin_p=%d Cout_p=%d)", a.Cin_p, a.Cout_p);

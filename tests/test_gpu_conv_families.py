@@ -31,9 +31,10 @@ def stack(hw, chans, res=True):
 
 
 # 25 = generation 2 with ns = 5 (fragment prefetch across K-steps), 51 = generation 5 with the weights two steps ahead,
-# 59 = generation 5 with register-staged producers (FID_PC_RS)
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 25, 51, 59])
-@pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2), ((37, 21), (64, 64), 3)])
+# 59 = generation 5 with register-staged producers (FID_PC_RS); 8 = two tiles per weight chunk (the (14, 14) x 5 case: an odd tile count)
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 25, 51, 59])
+@pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2), ((37, 21), (64, 64), 3),
+                                            ((14, 14), (128, 128), 5)])
 def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     if gen == 59:
