@@ -361,6 +361,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                         if ((c.gen == 2 || c.gen == 5) && c.ns == atoi(fn)) only.push_back(c);
                     if (!only.empty()) cands = only;
                 }
+                const float pc2_bias = getenv("FID_PC2_BIAS") ? (float)atof(getenv("FID_PC2_BIAS")) : 1.f;
                 hipEvent_t e0, e1;
                 FID_HIP(hipEventCreate(&e0));
                 FID_HIP(hipEventCreate(&e1));
@@ -378,7 +379,8 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                         FID_HIP(hipEventElapsedTime(&ms, e0, e1));
                         if (rep > 0) tmin = std::min(tmin, ms);
                     }
-                    const float score = c.ksplit > 1 ? tmin * 1.1f : tmin;
+                    float score = c.ksplit > 1 ? tmin * 1.1f : tmin;
+                    if (c.gen == 8) score *= pc2_bias;          // experiments: FID_PC2_BIAS < 1 prefers the two-tile kernel although it is slower alone
                     if (score < best) { best = score; plan = c; }
                 }
                 (void)hipEventDestroy(e0);
