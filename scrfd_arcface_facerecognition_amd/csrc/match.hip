@@ -122,6 +122,12 @@ int gemm_vs_gallery(fid_ctx *ctx, fid_gallery *g, const void *q, int n, int flag
     a.in_bytes = (unsigned)((size_t)n * g->dim * 2);
     a.w_bytes = (unsigned)((size_t)g->Gp * g->dim * 2);
     ConvPlan plan = conv_plan(a, ctx->num_cus, false);
+    // large galleries: the register-staged 128x128x64 kernel (measured 480-510 TFLOP/s against 350-390 for the LDS-DMA ring:
+    // with >= 2 tiles per CU resident its loads of the next K-step overlap the other workgroup's MFMAs, and the ring's
+    // fill rate -- one 1-KB piece per ~70 cycles and CU -- is what bounds a 128x128 tile)
+    if ((long long)cdiv(n, 128) * cdiv(g->Gp, 128) >= 2LL * ctx->num_cus && g->dim % 64 == 0 && !getenv("FID_MATCH_DMA")) {
+        plan.gen = 1; plan.bm = 128; plan.bn = 128; plan.bk = 64; plan.ksplit = 1; plan.partial_bytes = 0;
+    }
     return conv_launch(ctx, a, plan);
 }
 
