@@ -27,6 +27,7 @@ struct ConvArgs {
     int act, flags, nsig;
     int res_H, res_W, res_Cp;
     int tiles_m, tiles_n;
+    int tm_fast;   // tile order: 0 = the cout tiles of a pixel tile are consecutive (convs: few cout tiles, weights stay in L2), 1 = the pixel tiles of a cout tile are (gallery match: few query tiles, each gallery tile is fetched from HBM once)
     unsigned in_bytes, w_bytes;
 };
 

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs a) {
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tn = L % a.tiles_n, tm = L / a.tiles_n;
+    const int tn = a.tm_fast ? L / a.tiles_m : L % a.tiles_n, tm = a.tm_fast ? L % a.tiles_m : L / a.tiles_n;
     const int split = blockIdx.y;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256, (NS * (BM + (BN + 256 / (BK / 8) - 1) / (
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
     const int Lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tn = Lid % a.tiles_n, tm = Lid / a.tiles_n;
+    const int tn = a.tm_fast ? Lid / a.tiles_m : Lid % a.tiles_n, tm = a.tm_fast ? Lid % a.tiles_m : Lid / a.tiles_n;
     const int split = blockIdx.y;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(384, ((NS * (BM + (BN + 256 / (BK / 8) - 1) / 
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
     const int Lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tn = Lid % a.tiles_n, tm = Lid / a.tiles_n;
+    const int tn = a.tm_fast ? Lid / a.tiles_m : Lid % a.tiles_n, tm = a.tm_fast ? Lid % a.tiles_m : Lid / a.tiles_n;
     const int split = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 

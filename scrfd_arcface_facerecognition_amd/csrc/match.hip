@@ -119,6 +119,7 @@ int gemm_vs_gallery(fid_ctx *ctx, fid_gallery *g, const void *q, int n, int flag
     a.M = n;
     a.act = ACT_NONE;
     a.flags = flags;
+    a.tm_fast = getenv("FID_MATCH_TN_FAST") ? 0 : 1;   // the query tiles of one gallery tile run together: the gallery streams from HBM once
     a.in_bytes = (unsigned)((size_t)n * g->dim * 2);
     a.w_bytes = (unsigned)((size_t)g->Gp * g->dim * 2);
     ConvPlan plan = conv_plan(a, ctx->num_cus, false);
