@@ -41,6 +41,7 @@ extern "C" {
 typedef struct fid_ctx fid_ctx;         /* device + stream + scratch */
 typedef struct fid_net fid_net;         /* a compiled conv net (layer table + packed weights) */
 typedef struct fid_gallery fid_gallery; /* L2-normalised fp16 gallery resident in HBM */
+typedef struct fid_comm fid_comm;       /* one rank of an RCCL communicator (one process per GPU) */
 
 /* ---- library / context -------------------------------------------------------------------- */
 int fid_abi_version(void);
@@ -68,6 +69,14 @@ int fid_pinned_alloc(fid_ctx *ctx, size_t bytes, void **hptr);
 int fid_pinned_free(fid_ctx *ctx, void *hptr);
 int fid_upload_async(fid_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes);
 int fid_upload_wait(fid_ctx *ctx);
+/* Per-buffer ordering for double buffering (slot = one device staging buffer, 0 <= slot < FID_UPLOAD_SLOTS):
+ * fid_upload_release(slot) marks the compute work enqueued so far as the last reader of that buffer;
+ * fid_upload_async_slot copies into it after ONLY that release (so the upload of batch i+1 overlaps the compute of
+ * batch i, which reads the other buffer); fid_upload_wait_slot makes the compute stream wait for that upload. */
+#define FID_UPLOAD_SLOTS 4
+int fid_upload_release(fid_ctx *ctx, int slot);
+int fid_upload_async_slot(fid_ctx *ctx, int slot, void *dst_dev, const void *src_pinned, size_t bytes);
+int fid_upload_wait_slot(fid_ctx *ctx, int slot);
 
 /* ---- timing with HIP events on the context's stream (bench.py roofline leg) ----------------- */
 #define FID_MAX_EVENTS 64
@@ -97,6 +106,12 @@ int fid_net_tensor(fid_net *net, int tensor_id, void **dptr, int dims[4], int *d
 /* per-op device time of the last fid_net_run_profiled (ms per op, n_ops floats) */
 int fid_net_run_profiled(fid_ctx *ctx, fid_net *net, const uint8_t *images_dev, int batch,
                          float *op_ms);
+/* Kernel plans (per conv op and batch size the executor times its candidate kernels at first use and keeps the fastest).
+ * Text lines keyed by device name + layer-table hash; a loaded plan replaces the timing, so two boxes run the same
+ * kernels / fp32 summation orders and return bit-identical outputs.  Environment FID_PLAN=<file>: load at
+ * fid_net_create, append every new pick.  (No reference analogue: onnxruntime picks its kernels internally.) */
+int fid_net_plan_save(fid_net *net, const char *path);
+int fid_net_plan_load(fid_net *net, const char *path, int *n_loaded);
 /* algorithmic cost of one image through the net: multiply-accumulates (true channel counts) */
 int fid_net_macs(fid_net *net, double *macs_per_image);
 
@@ -172,6 +187,29 @@ int fid_gallery_data(fid_gallery *g, void **unit_rows_dev);
 int fid_gallery_topk(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, int k, float thresh,
                      int32_t *idx_dev, float *score_dev);
 int fid_gallery_set_rows(fid_ctx *ctx, fid_gallery *g, const int32_t *rows_host, const float *emb_host, int n);
+/* Gallery sharded over ranks by contiguous row blocks (the 1 M-entry variant of main.py:136-142):
+ * fid_match_keys scans THIS rank's rows (global index of its row 0 = first_row) for all n queries and writes one
+ * packed key per query, (order-preserving bits of the score << 32) | ~global_index; after the ranks' key arrays
+ * have been all-gathered ([parts, n], 8 bytes per query and rank) fid_match_merge takes the maximum key per query
+ * = the best score, lowest global index on ties, and applies the strict '>' threshold like fid_match. */
+int fid_match_keys(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, int first_row,
+                   uint64_t *keys_dev);
+int fid_match_merge(fid_ctx *ctx, const uint64_t *keys_dev, int parts, int n, int G_total, float thresh,
+                    int32_t *idx_dev, float *score_dev);
+
+/* ---- the path's one collective (no reference analogue: the reference is single-process; spec = BASELINE.json
+ * north_star "a single RCCL all-gather over xGMI of per-rank embeddings before the gallery match").
+ * One process per GPU.  Rank 0 calls fid_comm_unique_id and the host hands the FID_COMM_ID_BYTES bytes to every
+ * rank (file, environment, MPI, a torch.distributed store ...); every rank then calls fid_comm_init_rank (collective,
+ * blocks until all ranks arrived).  fid_allgather enqueues ncclAllGather on the context's stream:
+ * recv_dev [nranks][bytes_per_rank] <- each rank's send_dev, in rank order. */
+#define FID_COMM_ID_BYTES 128
+int fid_comm_unique_id(void *id_out, size_t bytes);
+int fid_comm_init_rank(fid_ctx *ctx, int nranks, int rank, const void *id, size_t bytes, fid_comm **out);
+int fid_comm_destroy(fid_ctx *ctx, fid_comm *comm);
+int fid_comm_info(fid_comm *comm, int *nranks, int *rank);
+int fid_allgather(fid_ctx *ctx, fid_comm *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+
 /* full cosine matrix fp32 [n, G_padded] (row stride = G_padded, a multiple of 32; columns >= G are
  * 0): tests / compute_similarity parity.  Caller-allocated device memory. */
 int fid_cosine_matrix(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n,

@@ -25,9 +25,13 @@ def gallery_scan(embedding, gallery, similarity_thresh):
 def match_batch(embeddings, gallery, similarity_thresh):
     """Vectorised equivalent of gallery_scan for many embeddings (fp32 numpy, used at sizes where
     the python loop would take minutes).  argmax returns the first maximum, like the strict '>'."""
-    e = embeddings / np.linalg.norm(embeddings, axis=1, keepdims=True)
-    g = gallery / np.linalg.norm(gallery, axis=1, keepdims=True)
-    s = e @ g.T
+    with np.errstate(invalid="ignore", divide="ignore"):
+        e = embeddings / np.linalg.norm(embeddings, axis=1, keepdims=True)
+        g = gallery / np.linalg.norm(gallery, axis=1, keepdims=True)
+        s = e @ g.T
+    # an all-zero target or embedding gives NaN similarities; in the reference loop `nan > max_similarity` is False, so such
+    # an entry is skipped and the scan goes on (main.py:139-140)
+    s = np.where(np.isnan(s), -np.inf, s)
     idx = s.argmax(axis=1)
     best = s[np.arange(len(e)), idx]
     ok = (best > 0) & (best > similarity_thresh)

@@ -37,6 +37,9 @@ SIGNATURES = {
     "fid_pinned_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fid_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "fid_upload_wait": (C.c_int, [C.c_void_p]),
+    "fid_upload_release": (C.c_int, [C.c_void_p, C.c_int]),
+    "fid_upload_async_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fid_upload_wait_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "fid_event_record": (C.c_int, [C.c_void_p, C.c_int]),
     "fid_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_f32_p]),
     "fid_net_create": (C.c_int, [C.c_void_p, c_i32_p, C.c_int, c_i32_p, C.c_int, C.c_void_p, C.c_size_t,
@@ -46,6 +49,8 @@ SIGNATURES = {
     "fid_net_set_sub_batch": (C.c_int, [C.c_void_p, C.c_int]),
     "fid_net_tensor": (C.c_int, [C.c_void_p, C.c_int, c_void_pp, c_int_p, c_int_p]),
     "fid_net_run_profiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_f32_p]),
+    "fid_net_plan_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "fid_net_plan_load": (C.c_int, [C.c_void_p, C.c_char_p, c_int_p]),
     "fid_net_macs": (C.c_int, [C.c_void_p, c_f64_p]),
     "fid_letterbox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 c_f64_p]),
@@ -69,6 +74,13 @@ SIGNATURES = {
     "fid_gallery_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "fid_gallery_set_rows": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p, C.c_void_p, C.c_int]),
     "fid_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "fid_match_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fid_match_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "fid_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "fid_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, c_void_pp]),
+    "fid_comm_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fid_comm_info": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "fid_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "fid_cosine_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
 }
 

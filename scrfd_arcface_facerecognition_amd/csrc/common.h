@@ -86,6 +86,8 @@ struct fid_ctx {
     hipEvent_t events[FID_MAX_EVENTS] = {};
     hipStream_t copy_stream = nullptr;   // H2D uploads that overlap compute (video front-end)
     hipEvent_t copy_done = nullptr, compute_done = nullptr;
+    hipEvent_t slot_uploaded[FID_UPLOAD_SLOTS] = {}, slot_released[FID_UPLOAD_SLOTS] = {};   // per staging buffer
+    bool slot_has_upload[FID_UPLOAD_SLOTS] = {}, slot_has_release[FID_UPLOAD_SLOTS] = {};
     // SCRFD post-process state
     int cand_cap = 4096;
     int32_t *status_dev = nullptr;  // [0] max candidates seen, [1] max survivors seen

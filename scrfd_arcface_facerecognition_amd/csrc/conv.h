@@ -20,7 +20,8 @@ struct ConvArgs {
     const void *res;    // fp16 residual [B, res_H, res_W, res_Cp] or NULL
     void *out;          // fp16/fp32 [B, Ho, Wo, Cout_p]
     float *partial;     // split-K slabs fp32 [ksplit][M][Cout_p]
-    unsigned long long *amax;  // CF_ARGMAX: packed (sortable(value) << 32 | ~column) per row
+    unsigned long long *amax;  // CF_ARGMAX: packed (sortable(value) << 32 | ~(amax_col0 + column)) per row
+    int amax_col0;             // CF_ARGMAX: global index of column 0 (gallery shards)
     int H, W, Cin_p, Ho, Wo, Cout_p, w_rows;
     int kh, kw, stride, pad;
     int M, T, nchunk, ksteps, ksplit, ksteps_per_split;

@@ -124,7 +124,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs &a, f32x4 (&acc)[BN
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (co0 + j < a.Cout_p) {
-                        const unsigned long long key = ((unsigned long long)sortable(acc[ni][mi][j]) << 32) | (unsigned)(~(unsigned)(co0 + j));
+                        const float sv = acc[ni][mi][j];   // a NaN score can never win (`nan > best` is False in the reference scan)
+                        const unsigned long long key = ((unsigned long long)(sv == sv ? sortable(sv) : 0u) << 32) | (unsigned)(~(unsigned)(a.amax_col0 + co0 + j));
                         best = key > best ? key : best;
                     }
                 }

@@ -77,6 +77,10 @@ int fid_ctx_destroy(fid_ctx *ctx) {
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
     if (ctx->compute_done) (void)hipEventDestroy(ctx->compute_done);
+    for (int i = 0; i < FID_UPLOAD_SLOTS; i++) {
+        if (ctx->slot_uploaded[i]) (void)hipEventDestroy(ctx->slot_uploaded[i]);
+        if (ctx->slot_released[i]) (void)hipEventDestroy(ctx->slot_released[i]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FID_OK;
@@ -149,16 +153,22 @@ int fid_pinned_free(fid_ctx *ctx, void *hptr) {
     return FID_OK;
 }
 
-// enqueue a pinned-host -> device copy on the context's upload stream; it starts only after everything enqueued
-// so far on the compute stream has finished (the destination may still be read by earlier kernels)
-int fid_upload_async(fid_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes) {
-    FID_REQUIRE(ctx && dst_dev && src_pinned && bytes > 0, "bad args");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+static int ensure_copy_stream(fid_ctx *ctx) {
     if (!ctx->copy_stream) {
         FID_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
         FID_HIP(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
         FID_HIP(hipEventCreateWithFlags(&ctx->compute_done, hipEventDisableTiming));
     }
+    return FID_OK;
+}
+
+// enqueue a pinned-host -> device copy on the context's upload stream; it starts only after everything enqueued
+// so far on the compute stream has finished (the conservative form: the destination may still be read by ANY earlier kernel;
+// for double buffering use the slot form below, which waits only for the last reader of that buffer)
+int fid_upload_async(fid_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes) {
+    FID_REQUIRE(ctx && dst_dev && src_pinned && bytes > 0, "bad args");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_TRY(ensure_copy_stream(ctx));
     FID_HIP(hipEventRecord(ctx->compute_done, ctx->stream));
     FID_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->compute_done, 0));
     FID_HIP(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
@@ -171,6 +181,49 @@ int fid_upload_wait(fid_ctx *ctx) {
     FID_REQUIRE(ctx, "ctx is NULL");
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (ctx->copy_done) FID_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_done, 0));
+    return FID_OK;
+}
+
+// ---- per-buffer ordering for double / triple buffering: slot k names one device staging buffer.
+//   fid_upload_release(k)      "everything enqueued so far on the compute stream is the last reader of buffer k"
+//   fid_upload_async_slot(k)   copy into buffer k; waits ONLY for buffer k's release (not for the step that is running on
+//                              another buffer), so the upload of batch i+1 really overlaps the compute of batch i
+//   fid_upload_wait_slot(k)    the compute stream waits for buffer k's upload
+static int slot_events(fid_ctx *ctx, int slot) {
+    FID_REQUIRE(slot >= 0 && slot < FID_UPLOAD_SLOTS, "upload slot %d outside [0, %d)", slot, FID_UPLOAD_SLOTS);
+    FID_TRY(ensure_copy_stream(ctx));
+    if (!ctx->slot_uploaded[slot]) {
+        FID_HIP(hipEventCreateWithFlags(&ctx->slot_uploaded[slot], hipEventDisableTiming));
+        FID_HIP(hipEventCreateWithFlags(&ctx->slot_released[slot], hipEventDisableTiming));
+    }
+    return FID_OK;
+}
+
+int fid_upload_release(fid_ctx *ctx, int slot) {
+    FID_REQUIRE(ctx, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_TRY(slot_events(ctx, slot));
+    FID_HIP(hipEventRecord(ctx->slot_released[slot], ctx->stream));
+    ctx->slot_has_release[slot] = true;
+    return FID_OK;
+}
+
+int fid_upload_async_slot(fid_ctx *ctx, int slot, void *dst_dev, const void *src_pinned, size_t bytes) {
+    FID_REQUIRE(ctx && dst_dev && src_pinned && bytes > 0, "bad args");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_TRY(slot_events(ctx, slot));
+    if (ctx->slot_has_release[slot]) FID_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->slot_released[slot], 0));
+    FID_HIP(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    FID_HIP(hipEventRecord(ctx->slot_uploaded[slot], ctx->copy_stream));
+    ctx->slot_has_upload[slot] = true;
+    return FID_OK;
+}
+
+int fid_upload_wait_slot(fid_ctx *ctx, int slot) {
+    FID_REQUIRE(ctx, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_TRY(slot_events(ctx, slot));
+    if (ctx->slot_has_upload[slot]) FID_HIP(hipStreamWaitEvent(ctx->stream, ctx->slot_uploaded[slot], 0));
     return FID_OK;
 }
 

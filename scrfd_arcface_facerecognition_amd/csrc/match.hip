@@ -26,7 +26,10 @@ __global__ void __launch_bounds__(256) l2norm_rows(const float *__restrict__ x, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float nrm = sqrtf(ss);
-    for (int i = lane; i < dim; i += 64) out[(size_t)row * dim + i] = (_Float16)(r[i] / nrm);
+    // an all-zero (or non-finite) row becomes a ZERO row, never NaN: a zero row scores 0 against everything and a match
+    // needs a score > 0, which is what the reference's `nan > x == False` chain does with such a target (main.py:139-140)
+    const bool ok = nrm > 0.f && nrm < __builtin_inff();
+    for (int i = lane; i < dim; i += 64) out[(size_t)row * dim + i] = ok ? (_Float16)(r[i] / nrm) : (_Float16)0.f;
 }
 
 // top-k per query row of a [n, ld] fp32 score matrix (k <= 8): one wavefront per row, each lane keeps the
@@ -88,29 +91,37 @@ __global__ void __launch_bounds__(256) set_rows(const float *__restrict__ x, con
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float nrm = sqrtf(ss);
-    for (int i = lane; i < dim; i += 64) gal[(size_t)dst * dim + i] = nrm > 0.f ? (_Float16)(src[i] / nrm) : (_Float16)0.f;
+    const bool ok = nrm > 0.f && nrm < __builtin_inff();
+    for (int i = lane; i < dim; i += 64) gal[(size_t)dst * dim + i] = ok ? (_Float16)(src[i] / nrm) : (_Float16)0.f;
 }
 
-__global__ void __launch_bounds__(256) match_finalize(const unsigned long long *amax, int n, int G, float thresh, int *idx,
+// arg-max over `parts` key arrays (one per gallery shard; keys carry GLOBAL column indices, so the maximum key is the best
+// score and, among equal scores, the lowest gallery index -- the strict-'>' scan of main.py:139-140) + threshold
+__global__ void __launch_bounds__(256) match_finalize(const unsigned long long *amax, int parts, int n, int G, float thresh, int *idx,
                                                       float *score) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long key = amax[i];
+    unsigned long long key = amax[i];
+    for (int p = 1; p < parts; p++) {
+        const unsigned long long k = amax[(size_t)p * n + i];
+        key = k > key ? k : key;
+    }
     unsigned u = (unsigned)(key >> 32);
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
     const float s = __uint_as_float(u);
     const int j = (int)(~(unsigned)key);
-    const bool ok = key != 0ull && j < G && s > 0.f && s > thresh;
+    const bool ok = key != 0ull && j >= 0 && j < G && s > 0.f && s > thresh;
     idx[i] = ok ? j : -1;
     score[i] = ok ? s : 0.f;
 }
 
-int gemm_vs_gallery(fid_ctx *ctx, fid_gallery *g, const void *q, int n, int flags, void *out, unsigned long long *amax) {
+int gemm_vs_gallery(fid_ctx *ctx, fid_gallery *g, const void *q, int n, int flags, void *out, unsigned long long *amax, int col0 = 0) {
     ConvArgs a{};
     a.in = q;
     a.w = g->unit_f16;
     a.out = out;
     a.amax = amax;
+    a.amax_col0 = col0;
     a.H = a.W = a.Ho = a.Wo = 1;
     a.Cin_p = g->dim;
     a.Cout_p = g->Gp;
@@ -194,8 +205,30 @@ int fid_match(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, fl
     FID_TRY(fid::get_scratch(ctx, 2, (size_t)n * 8, &ws));
     FID_HIP(hipMemsetAsync(ws, 0, (size_t)n * 8, ctx->stream));
     FID_TRY(fid::gemm_vs_gallery(ctx, g, query_f16_dev, n, fid::CF_ARGMAX, nullptr, (unsigned long long *)ws));
-    hipLaunchKernelGGL(fid::match_finalize, dim3(fid::cdiv(n, 256)), dim3(256), 0, ctx->stream, (const unsigned long long *)ws, n, g->G,
+    hipLaunchKernelGGL(fid::match_finalize, dim3(fid::cdiv(n, 256)), dim3(256), 0, ctx->stream, (const unsigned long long *)ws, 1, n, g->G,
                        thresh, idx_dev, score_dev);
+    FID_HIP(hipGetLastError());
+    return FID_OK;
+}
+
+// Gallery sharded over ranks (the 1 M-entry variant): every rank scans ITS rows for all queries and emits one
+// packed key per query, (sortable(score) << 32) | ~(first_row + local index); the keys of all ranks are exchanged by one tiny
+// all-gather (8 bytes per query and rank) and fid_match_merge takes the maximum -- the same result as one scan of the whole
+// gallery, first index winning ties, because the shards are contiguous row blocks.
+int fid_match_keys(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, int first_row, uint64_t *keys_dev) {
+    FID_REQUIRE(ctx && g && query_f16_dev && keys_dev && n > 0 && first_row >= 0, "bad args");
+    FID_REQUIRE((long long)first_row + g->Gp < 0x7FFFFFFFll, "global gallery index overflows 31 bits");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipMemsetAsync(keys_dev, 0, (size_t)n * 8, ctx->stream));
+    return fid::gemm_vs_gallery(ctx, g, query_f16_dev, n, fid::CF_ARGMAX, nullptr, (unsigned long long *)keys_dev, first_row);
+}
+
+int fid_match_merge(fid_ctx *ctx, const uint64_t *keys_dev, int parts, int n, int G_total, float thresh, int32_t *idx_dev,
+                    float *score_dev) {
+    FID_REQUIRE(ctx && keys_dev && idx_dev && score_dev && parts > 0 && n > 0 && G_total > 0, "bad args");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipLaunchKernelGGL(fid::match_finalize, dim3(fid::cdiv(n, 256)), dim3(256), 0, ctx->stream, (const unsigned long long *)keys_dev, parts, n,
+                       G_total, thresh, idx_dev, score_dev);
     FID_HIP(hipGetLastError());
     return FID_OK;
 }

@@ -30,6 +30,10 @@ struct fid_net {
     std::map<std::pair<const void *, int>, Replay> replays;
     unsigned long long run_counter = 0;
     int graphs = 0;      // FID_GRAPH=1 turns the replay on (measured: no gain on this stack)
+    // persisted kernel plans (FID_PLAN=file / fid_net_plan_load): keyed by device name + a hash of the layer table, so that
+    // two boxes run the SAME kernels and fp32 summation orders and return bit-identical heads / embeddings
+    unsigned long long table_hash = 0;
+    std::string device_key, plan_path;
 };
 
 namespace fid {
@@ -277,6 +281,41 @@ TensorView view(const fid_net *net, int id, int first = 0) {
     return TensorView{(char *)net->slots[t[T_SLOT]] + per_image * first, t[T_C], t[T_CP], t[T_H], t[T_W], t[T_DTYPE]};
 }
 
+unsigned long long fnv1a(const void *p, size_t n, unsigned long long h = 1469598103934665603ull) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+// one line per pick:  <device>|<table hash>|<op>|<batch>|gen bm bn bk ksplit ns partial_bytes
+void plan_line(const fid_net *net, int oi, int batch, const ConvPlan &c, char *buf, size_t cap) {
+    snprintf(buf, cap, "%s|%016llx|%d|%d|%d %d %d %d %d %d %zu\n", net->device_key.c_str(), net->table_hash, oi, batch, c.gen, c.bm, c.bn,
+             c.bk, c.ksplit, c.ns, c.partial_bytes);
+}
+
+int plan_load(fid_net *net, const char *path, int *n_loaded) {
+    FILE *f = fopen(path, "r");
+    int n = 0;
+    if (f) {
+        char line[512];
+        while (fgets(line, sizeof(line), f)) {
+            char dev[256];
+            unsigned long long h = 0;
+            int oi = 0, batch = 0;
+            ConvPlan c{};
+            if (sscanf(line, "%255[^|]|%llx|%d|%d|%d %d %d %d %d %d %zu", dev, &h, &oi, &batch, &c.gen, &c.bm, &c.bn, &c.bk, &c.ksplit, &c.ns,
+                       &c.partial_bytes) != 11)
+                continue;
+            if (h != net->table_hash || net->device_key != dev || oi < 0 || oi >= net->n_ops || batch <= 0) continue;
+            net->tuned[oi][batch] = c;      // later lines win (a re-tuned pick is appended)
+            n++;
+        }
+        fclose(f);
+    }
+    if (n_loaded) *n_loaded = n;
+    return FID_OK;
+}
+
 // one op on images [first, first + batch) of the resident batch
 int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first, int batch, void *partial_ws) {
     const int32_t *op = &net->ops[(size_t)oi * FID_OP_WORDS];
@@ -366,6 +405,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 FID_HIP(hipEventCreate(&e0));
                 FID_HIP(hipEventCreate(&e1));
                 float best = 1e30f;
+                if (cands.empty()) { set_error("op %d: no kernel candidate", oi); return FID_E_STATE; }
                 plan = cands[0];
                 for (const ConvPlan &c : cands) {
                     if (c.partial_bytes > net->partial_cap) continue;
@@ -386,6 +426,14 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 (void)hipEventDestroy(e0);
                 (void)hipEventDestroy(e1);
                 cache[batch] = plan;
+                if (!net->plan_path.empty()) {                      // persist the pick (one O_APPEND line)
+                    if (FILE *pf = fopen(net->plan_path.c_str(), "a")) {
+                        char line[512];
+                        plan_line(net, oi, batch, plan, line, sizeof(line));
+                        fputs(line, pf);
+                        fclose(pf);
+                    }
+                }
                 if (getenv("FID_TUNE_LOG"))
                     fprintf(stderr, "[tune] op %d M=%d Cin_p=%d Cout_p=%d k=%d s=%d -> gen %d tile %dx%dx%d ns %d split %d (%.1f us)\n", oi, a.M,
                             a.Cin_p, a.Cout_p, a.kh, a.stride, plan.gen, plan.bm, plan.bn, plan.bk, plan.ns, plan.ksplit, best * 1e3f);
@@ -446,6 +494,9 @@ size_t partial_need(fid_ctx *ctx, fid_net *net, int batch) {
 int run_all(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float *op_ms) {
     FID_REQUIRE(ctx && net && images, "NULL argument");
     FID_REQUIRE(batch > 0 && batch <= net->max_batch, "batch %d outside [1, %d]", batch, net->max_batch);
+    // r01's recorded SIGSEGV (gpurun_out/gpu_tests_13.log): a working tree whose fid_net_create did not size `tuned` yet indexed
+    // tuned[op] of an empty vector at the first conv of the first net that ran.  The table is sized in fid_net_create; keep it checked.
+    FID_REQUIRE((int)net->tuned.size() == net->n_ops, "net: plan table has %zu entries for %d ops", net->tuned.size(), net->n_ops);
     std::lock_guard<std::mutex> lk(ctx->mu);
     void *partial_ws = nullptr;
     const int sbq = (!op_ms && net->sub_batch > 0) ? std::min(net->sub_batch, batch) : batch;
@@ -598,8 +649,52 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
     if (const char *e = getenv("FID_AUTOTUNE")) net->autotune = atoi(e);
     if (const char *e = getenv("FID_GRAPH")) net->graphs = atoi(e);
     net->tuned.resize(n_ops);
+    {
+        hipDeviceProp_t prop;
+        FID_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        char key[256];
+        snprintf(key, sizeof(key), "%s/%s/cus%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+        for (char *c = key; *c; c++)
+            if (*c == '|' || *c == '\n') *c = '_';
+        net->device_key = key;
+        unsigned long long h = fnv1a(net->ops.data(), net->ops.size() * sizeof(int32_t));
+        h = fnv1a(net->tensors.data(), net->tensors.size() * sizeof(int32_t), h);
+        h = fnv1a(&blob_bytes, sizeof(blob_bytes), h);
+        net->table_hash = h;
+    }
+    if (const char *e = getenv("FID_PLAN")) {
+        net->plan_path = e;
+        (void)plan_load(net, e, nullptr);
+    }
     *out = net;
     return FID_OK;
+}
+
+// Kernel plans of this net (per conv op and batch size: kernel family, tile, split-K) as text lines keyed by the device name
+// and a hash of the layer table.  fid_net_plan_save writes every pick made so far; fid_net_plan_load installs matching
+// lines (others are ignored) and returns their number -- a loaded pick is used instead of timing candidates, so outputs no
+// longer depend on which box tuned.  FID_PLAN=<file> does both automatically (load at create,
+// append every new pick).
+int fid_net_plan_save(fid_net *net, const char *path) {
+    FID_REQUIRE(net && path, "NULL argument");
+    FILE *f = fopen(path, "a");
+    FID_REQUIRE(f, "cannot open %s for appending", path);
+    char line[512];
+    for (int oi = 0; oi < net->n_ops; oi++)
+        for (const auto &kv : net->tuned[oi]) {
+            fid::plan_line(net, oi, kv.first, kv.second, line, sizeof(line));
+            fputs(line, f);
+        }
+    fclose(f);
+    return FID_OK;
+}
+
+int fid_net_plan_load(fid_net *net, const char *path, int *n_loaded) {
+    FID_REQUIRE(net && path, "NULL argument");
+    for (auto &kv : net->replays)      // recorded launch sequences no longer match
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    net->replays.clear();
+    return fid::plan_load(net, path, n_loaded);
 }
 
 int fid_net_set_sub_batch(fid_net *net, int sub_batch) {

@@ -71,6 +71,16 @@ class CompiledNet:
         buf = self.ctx.borrow(ptr, (batch, H, W, Cp), dt)
         return buf.download()[..., :Cc].astype(np.float32)
 
+    def save_plan(self, path: str):
+        """append this net's kernel picks (per conv op and batch size) to a plan file"""
+        check(self.ctx.lib.fid_net_plan_save(self.handle, str(path).encode()))
+
+    def load_plan(self, path: str) -> int:
+        """install the picks of a plan file that match this device and layer table; returns how many"""
+        n = C.c_int()
+        check(self.ctx.lib.fid_net_plan_load(self.handle, str(path).encode(), C.byref(n)))
+        return n.value
+
     def macs_per_image(self) -> float:
         v = C.c_double()
         check(self.ctx.lib.fid_net_macs(self.handle, C.byref(v)))

@@ -81,6 +81,14 @@ class FacePipeline:
         gallery.match_device(self.q if q is None else q, self.n_slots if n is None else n, thresh,
                              self.idx if idx is None else idx, self.score if score is None else score)
 
+    def match_keys(self, gallery: Gallery, q, n, first_row, keys):
+        """this rank's shard of a row-sharded gallery: one packed (score, global index) key per query"""
+        check(self.ctx.lib.fid_match_keys(self.ctx.handle, gallery.handle, _lib._ptr(q), int(n), int(first_row), _lib._ptr(keys)))
+
+    def match_merge(self, keys_all, parts, n, gallery_total, thresh, idx, score):
+        check(self.ctx.lib.fid_match_merge(self.ctx.handle, _lib._ptr(keys_all), int(parts), int(n), int(gallery_total),
+                                           float(thresh), _lib._ptr(idx), _lib._ptr(score)))
+
     def run_step(self, frames_dev, H, W, gallery: Gallery, thresh: float = 0.4):
         """One full pass over one batch; asynchronous (results stay on the device)."""
         self.detect(frames_dev, H, W)
@@ -134,15 +142,194 @@ def calibrate_detector_bias(ctx: Context, net, params, frames: np.ndarray, targe
     return out, shift
 
 
+# ---- gallery construction: reference main.py:78-105 ----------------------------------------------------
+
+def _read_image(path: str) -> Optional[np.ndarray]:
+    """cv2.imread stand-in for hosts without OpenCV: returns uint8 BGR [H,W,3] or None (like imread on a file
+    it cannot decode).  Uses OpenCV when importable; otherwise understands .npy arrays and binary PPM (P6)."""
+    try:
+        import cv2
+        return cv2.imread(path)
+    except ImportError:
+        pass
+    try:
+        if path.endswith(".npy"):
+            a = np.load(path, allow_pickle=False)
+            return np.ascontiguousarray(a, dtype=np.uint8) if a.ndim == 3 and a.shape[2] == 3 else None
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:2] == b"P6":
+            tok, pos = [], 2
+            while len(tok) < 3:                          # width, height, maxval (comments allowed)
+                while data[pos:pos + 1].isspace():
+                    pos += 1
+                if data[pos:pos + 1] == b"#":
+                    pos = data.index(b"\n", pos) + 1
+                    continue
+                end = pos
+                while not data[end:end + 1].isspace():
+                    end += 1
+                tok.append(int(data[pos:end])); pos = end
+            w, h, mx = tok
+            if mx != 255:
+                return None
+            rgb = np.frombuffer(data, np.uint8, count=w * h * 3, offset=pos + 1).reshape(h, w, 3)
+            return np.ascontiguousarray(rgb[..., ::-1])
+    except Exception:
+        return None
+    return None
+
+
+def build_targets_from_images(detector, recognizer, images: Sequence[np.ndarray], names: Sequence[str],
+                              paths: Optional[Sequence[str]] = None) -> List[Tuple[np.ndarray, str]]:
+    """The body of reference build_targets (main.py:91-103) for images already in memory:
+    per image `detect(image, max_num=1)` (:96), images without a face are skipped with a warning (:98-100),
+    the best face is embedded (`recognizer(image, kpss[0])`, :102) and `(embedding, name)` collected (:103),
+    in input order.  Images of one shape go through the detector, the alignment and the recogniser as ONE
+    batch each (detect_batch -> fid_align_crops -> get_feat); objects without the batched surface are driven
+    through the reference's per-image calls."""
+    import logging
+    assert len(images) == len(names)
+    kps_of: List[Optional[np.ndarray]] = [None] * len(images)
+    batched = hasattr(detector, "detect_batch") and hasattr(recognizer, "get_feat") and getattr(recognizer, "_native", False)
+    by_shape = {}
+    for i, im in enumerate(images):
+        by_shape.setdefault(tuple(im.shape), []).append(i)
+    emb_of: List[Optional[np.ndarray]] = [None] * len(images)
+    for shape, ids in by_shape.items():
+        if not batched:
+            for i in ids:
+                _, kpss = detector.detect(images[i], max_num=1)
+                if len(kpss):
+                    emb_of[i] = np.asarray(recognizer(images[i], kpss[0]), dtype=np.float32).reshape(-1)
+            continue
+        stack = np.ascontiguousarray(np.stack([images[i] for i in ids]), dtype=np.uint8)
+        dets = detector.detect_batch(stack, max_num=1)
+        hit = [k for k, (_, kpss) in enumerate(dets) if len(kpss)]
+        if not hit:
+            continue
+        ctx = recognizer.ctx
+        H, W = shape[:2]
+        n = len(hit)
+        kps = np.stack([dets[k][1][0].reshape(10) for k in hit]).astype(np.float32).reshape(n, 1, 10)
+        fr = ctx.to_device(stack[hit])
+        kp, cn = ctx.to_device(kps), ctx.to_device(np.ones(n, np.int32))
+        crops = ctx.empty((n, 112, 112, 3), np.uint8)
+        check(ctx.lib.fid_align_crops(ctx.handle, C.c_void_p(fr.ptr), n, H, W, C.c_void_p(kp.ptr), C.c_void_p(cn.ptr),
+                                      1, 1, C.c_void_p(crops.ptr), None))
+        feats = recognizer.get_feat(crops.download())
+        for k, e in zip(hit, feats):
+            emb_of[ids[k]] = np.ascontiguousarray(e, dtype=np.float32).reshape(-1)
+    targets = []
+    for i, name in enumerate(names):
+        if emb_of[i] is None:
+            logging.warning(f"No face detected in {paths[i] if paths else name}. Skipping...")
+            continue
+        targets.append((emb_of[i], name))
+    return targets
+
+
+def build_targets(detector, recognizer, params, *, loader=None) -> List[Tuple[np.ndarray, str]]:
+    """reference main.py:78-105, same signature: `params.faces_dir` is scanned with os.listdir (:91),
+    `name = filename[:-4]` (:92), every file is read (:95) and handed to build_targets_from_images.
+    `params` may also be the directory path itself.  Files the loader cannot decode are skipped."""
+    import logging
+    import os
+    faces_dir = params if isinstance(params, str) else params.faces_dir
+    loader = loader or _read_image
+    images, names, paths = [], [], []
+    for filename in os.listdir(faces_dir):
+        image_path = os.path.join(faces_dir, filename)
+        image = loader(image_path)
+        if image is None:
+            logging.warning(f"Cannot read {image_path}. Skipping...")
+            continue
+        images.append(image); names.append(filename[:-4]); paths.append(image_path)
+    return build_targets_from_images(detector, recognizer, images, names, paths)
+
+
+def gallery_from_targets(ctx: Context, targets: Sequence[Tuple[np.ndarray, str]]) -> Gallery:
+    """The `targets` list as a device-resident Gallery (what frame_processor scans, main.py:136-142)."""
+    assert len(targets) > 0, "no targets: every gallery image was skipped"
+    return Gallery(ctx, np.stack([t[0] for t in targets]).astype(np.float32), [t[1] for t in targets])
+
+
 # ---- multi-GPU step: the single collective -----------------------------------------------------
 
-def run_step_distributed(pipe: FacePipeline, frames_dev, H, W, gallery: Gallery, thresh, q_local, q_all, dist):
-    """Local detect/align/embed on this rank's frames, ONE all-gather of the unit embeddings, then this
-    rank matches its own block of the gathered matrix against the (replicated) gallery.
-    q_local / q_all are torch tensors ([n,512] / [world*n,512] fp16) on the pipeline's stream."""
+class Communicator:
+    """fid_comm: this rank's end of an RCCL communicator owned by libfaceid (include/faceid.h), so the collective runs
+    behind the C-ABI on the context's stream.  `exchange_id(id_bytes_or_None) -> id_bytes` is how the host hands rank 0's
+    128-byte rendezvous id to every rank (a torch.distributed broadcast, an MPI bcast, a file ...)."""
+
+    def __init__(self, ctx: Context, world: int, rank: int, exchange_id):
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
+        n = 128
+        buf = (C.c_uint8 * n)()
+        if rank == 0:
+            check(ctx.lib.fid_comm_unique_id(buf, n))
+        ident = exchange_id(bytes(buf) if rank == 0 else None)
+        assert len(ident) == n
+        h = C.c_void_p()
+        check(ctx.lib.fid_comm_init_rank(ctx.handle, self.world, self.rank, ident, n, C.byref(h)))
+        self.handle = h
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.world
+
+    def all_gather_into_tensor(self, out, inp):
+        """same call shape as torch.distributed's; `out` / `inp` are device buffers (anything _lib._ptr accepts)
+        and `inp` carries .nbytes or (numel, element_size)"""
+        nbytes = inp.nbytes if hasattr(inp, "nbytes") and not callable(inp.nbytes) else inp.numel() * inp.element_size()
+        check(self.ctx.lib.fid_allgather(self.ctx.handle, self.handle, _lib._ptr(inp), _lib._ptr(out), int(nbytes)))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.fid_comm_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+def _slice_ptr(buf, row0: int, row_bytes: int):
+    """device address of row `row0` of a 2-D device buffer (torch tensor / DeviceBuffer / raw int)"""
+    base = buf.data_ptr() if hasattr(buf, "data_ptr") else (buf.ptr if hasattr(buf, "ptr") else int(buf))
+    return base + row0 * row_bytes
+
+
+def run_step_distributed(pipe, frames_dev, H, W, gallery, thresh, q_local, q_all, dist, *, idx_all=None, score_all=None,
+                         match_scope: str = "all", keys_local=None, keys_all=None, gallery_first_row: int = 0,
+                         gallery_total: int = 0):
+    """One multi-GPU step: local detect / align / embed on this rank's frames, ONE all-gather of the
+    unit fp16 embeddings (the collective BASELINE.json's north_star names), then the gallery match on the gathered
+    matrix.  `dist` is torch.distributed (RCCL as backend "nccl", gloo in the CPU tests) or a `Communicator`
+    (the C-ABI's own RCCL communicator): anything with get_rank / get_world_size / all_gather_into_tensor.
+
+    q_local [n,512] / q_all [world*n,512] fp16 device buffers (pipe.q aliases q_local).
+
+    match_scope
+      "all"      (default; replicated gallery) every rank matches ALL world*n gathered queries, so every rank holds the
+                 whole batch's result list in idx_all / score_all [world*n] with no second collective -- the gather's
+                 output is what the match reads.
+      "own"      every rank matches only its own n rows of the gathered matrix into pipe.idx / pipe.score (the cheapest
+                 form when the host collects per-rank results itself).
+      "sharded"  gallery sharded by contiguous row blocks (the 1 M-entry variant): `gallery` holds rows
+                 [gallery_first_row, +G_local) of a gallery_total-row gallery; every rank scans its shard for all
+                 world*n queries (fid_match_keys), a second tiny all-gather exchanges the packed (score, index) keys
+                 (keys_local [world*n] u64 -> keys_all [world, world*n]), fid_match_merge takes the arg-max.
+    """
     pipe.detect(frames_dev, H, W)
     pipe.embed(frames_dev, H, W)            # writes q_local (pipe.q aliases it)
     dist.all_gather_into_tensor(q_all, q_local)
-    r = dist.get_rank()
+    r, world = dist.get_rank(), dist.get_world_size()
     n = pipe.n_slots
-    pipe.match(gallery, thresh, q=q_all[r * n:(r + 1) * n].data_ptr(), n=n)
+    if match_scope == "own":
+        pipe.match(gallery, thresh, q=_slice_ptr(q_all, r * n, 512 * 2), n=n)
+    elif match_scope == "all":
+        pipe.match(gallery, thresh, q=q_all, n=world * n, idx=idx_all, score=score_all)
+    elif match_scope == "sharded":
+        pipe.match_keys(gallery, q_all, world * n, gallery_first_row, keys_local)
+        dist.all_gather_into_tensor(keys_all, keys_local)
+        pipe.match_merge(keys_all, world, world * n, gallery_total, thresh, idx_all, score_all)
+    else:
+        raise ValueError(f"unknown match_scope {match_scope!r}")

@@ -42,8 +42,10 @@ class StreamRunner:
         self.dev = [ctx.empty(shape, np.uint8) for _ in range(2)]
 
     def _upload(self, k: int):
+        """copy pinned buffer k -> device buffer k on the upload stream; waits only for the last step that read dev[k]"""
         ctx = self.pipe.ctx
-        check(ctx.lib.fid_upload_async(ctx.handle, C.c_void_p(self.dev[k].ptr), C.c_void_p(self.host[k].ptr), self.host[k].nbytes))
+        check(ctx.lib.fid_upload_async_slot(ctx.handle, k, C.c_void_p(self.dev[k].ptr), C.c_void_p(self.host[k].ptr),
+                                            self.host[k].nbytes))
 
     def run(self, frames: Iterable[np.ndarray]) -> Iterator[List]:
         ctx, B = self.pipe.ctx, self.pipe.B
@@ -65,12 +67,13 @@ class StreamRunner:
         if n_cur:
             self._upload(cur)
         while n_cur:
-            check(ctx.lib.fid_upload_wait(ctx.handle))             # compute waits for batch `cur` (no host sync)
+            check(ctx.lib.fid_upload_wait_slot(ctx.handle, cur))   # compute waits for batch `cur` (no host sync)
             self.pipe.run_step(self.dev[cur], self.H, self.W, self.gallery, self.thr)
+            check(ctx.lib.fid_upload_release(ctx.handle, cur))     # dev[cur] is free again once this step has run
             nxt = cur ^ 1
             n_nxt = fill(nxt)                                       # host fills the other pinned buffer meanwhile
             if n_nxt:
-                self._upload(nxt)                                   # ordered after the step just enqueued
+                self._upload(nxt)                                   # dev[nxt]'s last reader was step i-1: starts NOW, beside step i
             res = self.pipe.results(self.gallery)                   # synchronises on batch `cur`
             for r in res[:n_cur]:
                 yield r

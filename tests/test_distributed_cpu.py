@@ -1,7 +1,8 @@
-"""CPU, world_size 2, gloo: the multi-GPU data path (frame sharding by rank + ONE all-gather of the
-per-rank unit embeddings + each rank matching its own block) gives the same result as one process.
-The GPU stages are replaced by the oracle here; the sharding / gather / indexing code is the
-product's (pipeline.shard_range and the all_gather_into_tensor layout)."""
+"""CPU, world_size 2, gloo: the product's multi-GPU step `pipeline.run_step_distributed` itself runs at N > 1
+(frame sharding by rank + ONE all-gather of the per-rank unit embeddings + the gallery match in its three scopes).
+The device stages are replaced by a duck-typed pipe backed by the oracle (there is no GPU here); the sharding, the
+collective calls, the gathered-matrix indexing and the sharded-gallery key exchange are the product's code."""
+import ctypes as C
 import os
 import sys
 
@@ -14,50 +15,128 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _worker(rank, world, port, q_all_np, gal, out_dir):
+def _sortable(score_f32):
+    u = score_f32.astype(np.float32).view(np.uint32).astype(np.uint64)
+    neg = (u & 0x80000000) != 0
+    return np.where(neg, (~u) & 0xFFFFFFFF, u | 0x80000000).astype(np.uint64)
+
+
+class OraclePipe:
+    """Same methods as FacePipeline (detect / embed / match / match_keys / match_merge, n_slots, idx, score); the
+    arithmetic is the oracle's.  Device pointers are host pointers here."""
+
+    def __init__(self, q_rank_f16, q_local, gal_rows):
+        self.n_slots = q_rank_f16.shape[0]
+        self._q_rank, self._q_local = q_rank_f16, q_local
+        self.idx = torch.full((self.n_slots,), -7, dtype=torch.int32)
+        self.score = torch.zeros((self.n_slots,), dtype=torch.float32)
+        self.calls = []
+
+    def detect(self, frames_dev, H, W):
+        self.calls.append("detect")
+
+    def embed(self, frames_dev, H, W):
+        self.calls.append("embed")
+        self._q_local.copy_(torch.from_numpy(self._q_rank))       # what fid_l2_normalize_f16 leaves in pipe.q
+
+    @staticmethod
+    def _rows(q, n):
+        if isinstance(q, int):                                    # a raw address into the gathered matrix ("own" scope)
+            return np.ctypeslib.as_array((C.c_uint16 * (n * 512)).from_address(q)).view(np.float16).reshape(n, 512).astype(np.float32)
+        return q.numpy()[:n].astype(np.float32)
+
+    def match(self, gallery, thresh, q=None, n=None, idx=None, score=None):
+        from oracle import match
+        i, s = match.match_batch(self._rows(q, n), gallery, thresh)
+        (self.idx if idx is None else idx)[:n] = torch.from_numpy(i)
+        (self.score if score is None else score)[:n] = torch.from_numpy(s)
+
+    def match_keys(self, gallery, q, n, first_row, keys):
+        e = self._rows(q, n)
+        g = gallery / np.linalg.norm(gallery, axis=1, keepdims=True)
+        s = (e / np.linalg.norm(e, axis=1, keepdims=True)) @ g.T
+        j = s.argmax(axis=1)
+        best = s[np.arange(n), j].astype(np.float32)
+        k = (_sortable(best) << np.uint64(32)) | ((~(j.astype(np.uint64) + np.uint64(first_row))) & np.uint64(0xFFFFFFFF))
+        keys.copy_(torch.from_numpy(k.view(np.int64)))
+
+    def match_merge(self, keys_all, parts, n, G_total, thresh, idx, score):
+        k = keys_all.numpy().view(np.uint64).reshape(parts, n).max(axis=0)
+        u = (k >> np.uint64(32)).astype(np.uint32)
+        u = np.where(u & 0x80000000, u & 0x7FFFFFFF, ~u).astype(np.uint32)
+        s = u.view(np.float32)
+        j = (~k & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        ok = (j < G_total) & (s > 0) & (s > thresh)
+        idx[:n] = torch.from_numpy(np.where(ok, j, -1).astype(np.int32))
+        score[:n] = torch.from_numpy(np.where(ok, s, 0).astype(np.float32))
+
+
+def _worker(rank, world, port, q_np, gal, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from oracle import match
-    from scrfd_arcface_facerecognition_amd.pipeline import shard_range
-    n_total = q_all_np.shape[0]
-    lo, hi = shard_range(n_total, world, rank)
+    from scrfd_arcface_facerecognition_amd.pipeline import run_step_distributed, shard_range
+    N = q_np.shape[0]
+    lo, hi = shard_range(N, world, rank)
     n = hi - lo
-    assert n * world == n_total
-    q_local = torch.from_numpy(q_all_np[lo:hi].copy())
-    q_all = torch.empty((world * n, q_all_np.shape[1]), dtype=q_local.dtype)
-    dist.all_gather_into_tensor(q_all, q_local)                    # the single collective
-    assert torch.equal(q_all, torch.from_numpy(q_all_np))            # every rank holds all embeddings, in frame order
-    mine = q_all[rank * n:(rank + 1) * n].numpy().astype(np.float32)
-    idx, score = match.match_batch(mine, gal, 0.4)
-    np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=idx, score=score, lo=lo, hi=hi)
+    assert n * world == N
+    res = {}
+    for scope in ("all", "own", "sharded"):
+        q_local = torch.zeros((n, 512), dtype=torch.float16)
+        q_all = torch.zeros((N, 512), dtype=torch.float16)
+        idx_all = torch.full((N,), -9, dtype=torch.int32)
+        score_all = torch.zeros((N,), dtype=torch.float32)
+        glo, ghi = shard_range(len(gal), world, rank) if scope == "sharded" else (0, len(gal))
+        pipe = OraclePipe(q_np[lo:hi], q_local, None)
+        kw = {}
+        if scope == "sharded":
+            kw = dict(keys_local=torch.zeros((N,), dtype=torch.int64), keys_all=torch.zeros((world * N,), dtype=torch.int64),
+                      gallery_first_row=glo, gallery_total=len(gal))
+        run_step_distributed(pipe, None, 640, 640, gal[glo:ghi], 0.4, q_local, q_all, dist, idx_all=idx_all,
+                             score_all=score_all, match_scope=scope, **kw)
+        assert pipe.calls == ["detect", "embed"]
+        assert torch.equal(q_all, torch.from_numpy(q_np))            # every rank holds all embeddings, in frame order
+        if scope == "own":
+            res[f"{scope}_idx"], res[f"{scope}_score"] = pipe.idx.numpy().copy(), pipe.score.numpy().copy()
+        else:
+            res[f"{scope}_idx"], res[f"{scope}_score"] = idx_all.numpy().copy(), score_all.numpy().copy()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), lo=lo, hi=hi, **res)
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_shard_range_partitions():
     from scrfd_arcface_facerecognition_amd.pipeline import shard_range
-    for n, w in ((512, 8), (64, 2), (10, 3), (7, 8)):
+    for n, w in ((512, 8), (64, 2), (10, 3), (7, 8), (100000, 8), (1000000, 8)):
         spans = [shard_range(n, w, r) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_gather_and_match(tmp_path):
+@pytest.mark.timeout(180)
+def test_two_rank_step_all_scopes(tmp_path):
     from oracle import match
     rng = np.random.default_rng(0)
     world, per_rank = 2, 8
-    gal = rng.standard_normal((50, 512)).astype(np.float32)
+    gal = rng.standard_normal((51, 512)).astype(np.float32)        # odd size: the two gallery shards differ in length
+    gal[40] = gal[7]                                                # an exact duplicate in the OTHER shard: index 7 must win
     emb = rng.standard_normal((world * per_rank, 512)).astype(np.float32)
     for i in range(0, len(emb), 2):
-        emb[i] = gal[rng.integers(0, 50)] + 0.5 * rng.standard_normal(512).astype(np.float32)
+        emb[i] = gal[rng.integers(0, 51)] + 0.5 * rng.standard_normal(512).astype(np.float32)
+    emb[2] = gal[40]
+    emb[12] = gal[50] + 0.1 * rng.standard_normal(512).astype(np.float32)   # best row = the last row of the last shard
     q = (emb / np.linalg.norm(emb, axis=1, keepdims=True)).astype(np.float16)       # what fid_l2_normalize_f16 emits
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, q, gal, str(tmp_path)), nprocs=world, join=True)
     ref_idx, ref_score = match.match_batch(q.astype(np.float32), gal, 0.4)
-    got_idx = np.concatenate([np.load(tmp_path / f"r{r}.npz")["idx"] for r in range(world)])
-    got_score = np.concatenate([np.load(tmp_path / f"r{r}.npz")["score"] for r in range(world)])
-    assert np.array_equal(got_idx, ref_idx) and np.allclose(got_score, ref_score)
-    assert (got_idx >= 0).sum() >= per_rank - 1
+    assert ref_idx[2] == 7 and ref_idx[12] == 50
+    outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    for r in range(world):                                          # "all" and "sharded": every rank holds the whole batch
+        for scope in ("all", "sharded"):
+            assert np.array_equal(outs[r][f"{scope}_idx"], ref_idx), (r, scope)
+            assert np.allclose(outs[r][f"{scope}_score"], ref_score, atol=1e-6), (r, scope)
+    own_idx = np.concatenate([outs[r]["own_idx"] for r in range(world)])           # "own": per-rank blocks, host concatenates
+    own_score = np.concatenate([outs[r]["own_score"] for r in range(world)])
+    assert np.array_equal(own_idx, ref_idx) and np.allclose(own_score, ref_score, atol=1e-6)
+    assert (ref_idx >= 0).sum() >= per_rank - 1

@@ -176,3 +176,55 @@ def test_vector_gallery_topk_upsert_delete(ctx):
                 assert hid == wid or abs(true[r, live.index(hid)] - ws) < 1e-3
     assert vg.search(queries[:2], k=1)[0][0][0] == "p3" and vg.search(queries[:2], k=1)[1][0][0] == "p120"
     assert all(h[0] != "p15" for h in vg.search(queries[2:3], k=8, score_threshold=0.0)[0])   # deleted id never returned
+
+
+def test_zero_gallery_row_does_not_poison_the_match(ctx):
+    """an all-zero target used to become a NaN fp16 row whose key outranked every real score and turned EVERY
+    query into Unknown.  The reference skips such a target (`nan > x` is False, main.py:139-140) and matches the others."""
+    rng = np.random.default_rng(17)
+    G, n = 300, 40
+    gallery = rng.standard_normal((G, 512)).astype(np.float32)
+    gallery[0] = 0.0
+    gallery[131] = 0.0
+    emb = rng.standard_normal((n, 512)).astype(np.float32)
+    tgt = rng.integers(1, G, n)
+    tgt[tgt == 131] = 132
+    for i in range(0, n, 2):
+        emb[i] = gallery[tgt[i]] + 0.3 * rng.standard_normal(512).astype(np.float32)
+    emb[3] = 0.0                                                       # an all-zero query as well
+    idx, sc, cm = gpu_match(ctx, emb, gallery, 0.4)
+    assert np.isfinite(cm).all() and not cm[:, 0].any() and not cm[:, 131].any() and not cm[3].any()
+    oi, osim = match.match_batch(emb, gallery, 0.4)
+    assert np.array_equal(idx, oi) and np.abs(sc - osim).max() < 1e-3
+    for i in range(0, n, 2):
+        j, s = match.gallery_scan(emb[i], gallery, 0.4)               # the reference-structured python loop itself
+        assert idx[i] == j == tgt[i] and abs(sc[i] - s) < 1e-3
+    assert idx[3] == -1 and sc[3] == 0.0
+
+
+def test_match_on_vector_gallery_free_rows(ctx):
+    """fid_match on a VectorGallery's inner gallery: its free capacity rows are zero rows (never NaN) and never match."""
+    from scrfd_arcface_facerecognition_amd._lib import check
+    from scrfd_arcface_facerecognition_amd.engine import VectorGallery
+    rng = np.random.default_rng(18)
+    vg = VectorGallery(ctx, 512, capacity=64)
+    emb = rng.standard_normal((10, 512)).astype(np.float32)
+    vg.upsert([f"p{i}" for i in range(10)], emb)
+    vg.delete(["p4"])
+    rows = ctx.borrow(__import__("scrfd_arcface_facerecognition_amd.engine", fromlist=["_gallery_ptr"])._gallery_ptr(vg._gal),
+                      (vg._gal.Gp, 512), np.float16).download()
+    assert np.isfinite(rows.astype(np.float32)).all()
+    queries = np.concatenate([emb + 0.2 * rng.standard_normal((10, 512)).astype(np.float32), rng.standard_normal((3, 512)).astype(np.float32)])
+    n = len(queries)
+    e = ctx.to_device(queries)
+    q = ctx.empty((n, 512), np.float16)
+    check(ctx.lib.fid_l2_normalize_f16(ctx.handle, C.c_void_p(e.ptr), n, 512, C.c_void_p(q.ptr)))
+    idx, sc = ctx.empty((n,), np.int32), ctx.empty((n,), np.float32)
+    vg._gal.match_device(q, n, 0.4, idx, sc)
+    idx, sc = idx.download(), sc.download()
+    for i in range(10):
+        if i == 4:
+            assert idx[i] == -1
+        else:
+            assert vg.id_of[int(idx[i])] == f"p{i}" and sc[i] > 0.9
+    assert (idx[10:] == -1).all()

@@ -193,3 +193,142 @@ def test_pipeline_matches_frame_by_frame_oracle(ctx):
                 top2 = np.sort(sims)[-2:]
                 if top2[1] - top2[0] > 3e-3:
                     assert name == (gallery.names[j] if j >= 0 else "Unknown")
+
+
+def test_build_targets_matches_reference_semantics(ctx, tmp_path, caplog):
+    """a19, reference main.py:78-105: per gallery image detect(max_num=1) -> skip + warn when no face -> embed the best face
+    -> (embedding, name) with name = filename[:-4], in listing order.  Checked against the frame-by-frame oracle
+    (detector decisions from the GPU heads, see test_detect_equals_oracle_on_the_gpu_heads), both for images in memory
+    and for a directory (files written as .npy / .ppm, the formats the loader reads without OpenCV)."""
+    import logging
+    from models import SCRFD, ArcFace
+    from scrfd_arcface_facerecognition_amd.pipeline import (build_targets, build_targets_from_images, calibrate_detector_bias,
+                                                            gallery_from_targets)
+    from scrfd_arcface_facerecognition_amd.session import HipSession
+    from scrfd_arcface_facerecognition_amd import archs
+    rng = np.random.default_rng(31)
+    n_img = 6
+    images = [rng.integers(0, 256, (320, 320, 3), dtype=np.uint8) for _ in range(n_img)]
+    images[2] = np.zeros((320, 320, 3), np.uint8)
+    images[4] = np.full((320, 320, 3), 255, np.uint8)
+    names = ["alice", "bob", "blank", "carol", "white", "dave"]
+    det_net = archs.scrfd_500m((320, 320))
+    det_P, _ = calibrate_detector_bias(ctx, det_net, archs.synth_params(det_net, 5), np.stack([images[i] for i in (0, 1, 3, 5)]),
+                                       target=30, max_batch=4)
+    # fp32 oracle scores decide which images have a face at all: put conf_thres into the widest gap of the per-image maxima
+    blob = oalign.blob_from_images(images, det_net.in_scale, det_net.in_mean)
+    mx = []
+    for b in range(n_img):
+        outs = onets.scrfd_session_outputs(det_net, det_P, blob[b:b + 1])
+        mx.append(max(float(o.max()) for o in outs[:3]))
+    srt = np.sort(mx)
+    gaps = srt[1:] - srt[:-1]
+    k = int(np.argmax(gaps))
+    assert gaps[k] > 0.02, mx
+    thr = float((srt[k] + srt[k + 1]) / 2)
+    has_face = [m > thr for m in mx]
+    assert any(has_face) and not all(has_face), mx                    # at least one image is skipped
+    detector = SCRFD("synthetic:scrfd_500m?seed=5", input_size=(320, 320), conf_thres=thr, max_batch=8)
+    detector.session = HipSession(None, ctx=detector.ctx, net=det_net, params=det_P, max_batch=8)
+    recognizer = ArcFace("synthetic:arcface_mbf?seed=5")
+    rec_net, rec_P = recognizer.session.net, recognizer.session.params
+    with caplog.at_level(logging.WARNING):
+        targets = build_targets_from_images(detector, recognizer, images, names)
+    assert [t[1] for t in targets] == [nm for nm, h in zip(names, has_face) if h]
+    assert sum("No face detected" in r.getMessage() for r in caplog.records) == has_face.count(False)
+    # oracle per image, landmarks from the GPU heads of the batched run (the compiled net still holds that batch)
+    cn = detector.session.compiled((320, 320))
+    ti = 0
+    for b in range(n_img):
+        if not has_face[b]:
+            continue
+        heads = []
+        for part in range(3):
+            for name in cn.low.outputs:
+                h = cn.low.heads[name]
+                off, c = (h["score"], h["bbox"], h["kps"])[part]
+                heads.append(np.ascontiguousarray(cn.read(name, n_img)[b][..., off:off + 2 * c]).reshape(-1, c))
+        odet, okps = pp.detect_from_heads(heads, (320, 320), (320, 320), thr, 0.4, 1, "max")
+        assert len(okps) == 1
+        ref, _ = opipe.embed(images[b], okps[0], rec_net, rec_P)
+        e = targets[ti][0]
+        assert e.shape == (512,) and e.dtype == np.float32
+        assert 1 - float(ref @ e / np.linalg.norm(ref) / np.linalg.norm(e)) < 1e-3
+        # the per-image reference call sequence gives the same vector as the batched path (batch-1 vs batch-n kernels: fp16 noise)
+        _, kpss = detector.detect(images[b], max_num=1)
+        assert np.array_equal(kpss[0], okps[0])
+        e1 = recognizer(images[b], kpss[0])
+        assert 1 - float(e1 @ e / np.linalg.norm(e1) / np.linalg.norm(e)) < 1e-3
+        ti += 1
+    assert ti == len(targets)
+    # directory form: name = filename[:-4]; unreadable files are skipped
+    d = tmp_path / "faces"
+    d.mkdir()
+    for nm, im in zip(names, images):
+        if nm in ("bob", "white"):
+            with open(d / f"{nm}.ppm", "wb") as f:
+                f.write(b"P6\n# synthetic\n320 320\n255\n" + np.ascontiguousarray(im[..., ::-1]).tobytes())
+        else:
+            np.save(d / f"{nm}.npy", im)
+    (d / "notes.txt").write_text("not an image")
+    t2 = build_targets(detector, recognizer, str(d))
+    by_name = {nm: e for e, nm in t2}
+    assert sorted(by_name) == sorted(t[1] for t in targets)
+    for e, nm in targets:
+        assert np.array_equal(by_name[nm], e)
+    gal = gallery_from_targets(ctx, targets)
+    assert gal.G == len(targets) and gal.names == [t[1] for t in targets]
+    from utils.helpers import match_gallery
+    idx, sc = match_gallery(np.stack([t[0] for t in targets]), gal, 0.4)
+    assert np.array_equal(idx, np.arange(len(targets))) and np.abs(sc - 1).max() < 1e-3
+    gal.close()
+
+
+def test_one_context_from_two_threads(ctx, monkeypatch):
+    """b4 (SURVEY 8b threading; the reference's product layer calls one shared model from <= 4 worker threads,
+    smart_face_recognition.py:1954-1957): two Python threads drive ONE fid_ctx (and a second ctx of its own) through
+    fid_net_run / fid_match concurrently; every result equals the serial run bit for bit."""
+    import threading
+    from scrfd_arcface_facerecognition_amd import archs
+    from scrfd_arcface_facerecognition_amd._lib import Context
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
+    monkeypatch.setenv("FID_AUTOTUNE", "0")       # all four nets on the same (heuristic) kernel plans -> same summation order
+    rng = np.random.default_rng(41)
+    net = archs.mobilefacenet()
+    P = archs.synth_params(net, 4)
+    crops = [rng.integers(0, 256, (4, 112, 112, 3), dtype=np.uint8) for _ in range(2)]
+    gal_host = rng.standard_normal((700, 512)).astype(np.float32)
+    other = Context(0)
+
+    def setup(c):
+        return [CompiledNet(c, net, P, max_batch=4) for _ in range(2)], Gallery(c, gal_host)
+
+    def work(c, cn, gal, imgs, out, reps):
+        from utils.helpers import match_gallery
+        for _ in range(reps):
+            cn.run(imgs)
+            e = cn.read(cn.low.outputs[0], len(imgs)).reshape(len(imgs), -1)
+            idx, sc = match_gallery(e, gal, 0.0, ctx=c)
+            out.append((e.copy(), idx.copy(), sc.copy()))
+
+    nets_a, gal_a = setup(ctx)
+    nets_b, gal_b = setup(other)
+    serial = []
+    for t in range(2):
+        o = []
+        work(ctx, nets_a[t], gal_a, crops[t], o, 1)
+        serial.append(o[0])
+    outs = [[], [], [], []]
+    threads = [threading.Thread(target=work, args=(ctx, nets_a[0], gal_a, crops[0], outs[0], 6)),
+               threading.Thread(target=work, args=(ctx, nets_a[1], gal_a, crops[1], outs[1], 6)),       # same ctx, other thread
+               threading.Thread(target=work, args=(other, nets_b[0], gal_b, crops[0], outs[2], 6)),     # an independent ctx
+               threading.Thread(target=work, args=(other, nets_b[1], gal_b, crops[1], outs[3], 6))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for k, o in enumerate(outs):
+        assert len(o) == 6
+        for e, idx, sc in o:
+            assert np.array_equal(e, serial[k % 2][0]) and np.array_equal(idx, serial[k % 2][1]) and np.array_equal(sc, serial[k % 2][2])
+    other.close()

@@ -185,3 +185,66 @@ def test_graph_replay_matches_eager(ctx, monkeypatch):
     for k, x in zip(net.outputs, got_b):
         assert np.array_equal(x, cn.read(k, 2))
     other.close(); eager.close(); cn.close()
+
+
+def test_first_run_autotune_at_unseen_shapes(ctx, monkeypatch):
+    """Regression for r01's recorded SIGSEGV in fid_net_run (gpurun_out/gpu_tests_13.log: the first net that ran after the
+    per-layer autotuner landed crashed on the host -- the plan table `tuned` was indexed before fid_net_create sized it).
+    A net whose (input size, batch) the process has never seen runs with the autotuner ON: every conv times its candidates
+    on first use (incl. split-K candidates against a small batch-1 workspace), at three batch sizes in a row, and the
+    results agree with the heuristic-plan run of the same net."""
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    monkeypatch.setenv("FID_AUTOTUNE", "1")
+    net = archs.scrfd_500m((224, 288))
+    P = archs.synth_params(net, seed=9)
+    rng = np.random.default_rng(5)
+    images = rng.integers(0, 256, (3, 224, 288, 3), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=3)
+    outs = {}
+    for b in (1, 3, 2):                                   # each batch size tunes afresh; 1 first (smallest split-K workspace)
+        cn.run(images[:b])
+        outs[b] = {k: cn.read(k, b) for k in net.outputs}
+    cn.close()
+    monkeypatch.setenv("FID_AUTOTUNE", "0")
+    cn0 = CompiledNet(ctx, net, P, max_batch=3)
+    cn0.run(images)
+    for k in net.outputs:
+        ref = cn0.read(k, 3)
+        for b in (1, 2, 3):
+            assert np.abs(outs[b][k] - ref[:b]).max() < 2e-2, (k, b)      # other kernels / summation orders: fp16 noise only
+    cn0.close()
+
+
+def test_plan_file_makes_runs_bit_identical(ctx, monkeypatch, tmp_path):
+    """FID_PLAN / fid_net_plan_save / fid_net_plan_load: the autotuner's picks are persisted per (device, layer table, op,
+    batch); a net that loads them times nothing and reproduces the tuned net's outputs bit for bit (two boxes with the same
+    plan file return identical heads), while another layer table ignores the file."""
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    net = archs.scrfd_500m((160, 192))
+    P = archs.synth_params(net, seed=3)
+    images = np.random.default_rng(2).integers(0, 256, (2, 160, 192, 3), dtype=np.uint8)
+    plan = tmp_path / "mi355x.plan"
+    monkeypatch.setenv("FID_AUTOTUNE", "1")
+    monkeypatch.setenv("FID_PLAN", str(plan))
+    a = CompiledNet(ctx, net, P, max_batch=2)
+    a.run(images)
+    ref = {k: a.read(k, 2) for k in net.outputs}
+    a.close()
+    lines = plan.read_text().splitlines()
+    n_conv = sum(1 for l in lines if l.count("|") == 4)
+    assert n_conv == len(lines) and n_conv >= 20
+    monkeypatch.delenv("FID_PLAN")
+    monkeypatch.setenv("FID_AUTOTUNE", "0")               # no timing at all: picks come from the file
+    b = CompiledNet(ctx, net, P, max_batch=2)
+    assert b.load_plan(str(plan)) == n_conv
+    b.run(images)
+    for k in net.outputs:
+        assert np.array_equal(b.read(k, 2), ref[k]), k
+    out2 = tmp_path / "copy.plan"
+    b.save_plan(str(out2))
+    assert sorted(out2.read_text().splitlines()) == sorted(set(lines))
+    b.close()
+    other = archs.scrfd_500m((160, 160))                  # another layer table: nothing matches
+    c = CompiledNet(ctx, other, P, max_batch=2)
+    assert c.load_plan(str(plan)) == 0
+    c.close()
