@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Headline benchmark: faces/s end-to-end (det + align + embed + match) on MI355X.
+"""Headline benchmark: faces/s end-to-end (det + align + embed + match) on MI355X; embed cosine delta vs the oracle.
 
-Workload (BASELINE.json configs[1]): SCRFD-10G + ArcFace-R50 (fp16 MFMA, fp32 accumulate), batch = 64
-synthetic 640x640 frames per GPU, 1k-entry gallery, F = 1 face kept per frame (the reference's
---max-num 1, main.py:55-60).  One process per GPU; frames shard by rank, one RCCL all-gather of the
-per-rank unit embeddings before the gallery match (weak scaling: 64 frames per GPU).
+Workload at N = 1 (BASELINE.json configs[1]): SCRFD-10G + ArcFace-R50 (fp16 MFMA, fp32 accumulate), batch = 64
+synthetic 640x640 frames per GPU, 1k-entry gallery, F = 1 face kept per frame (the reference's --max-num 1,
+main.py:55-60).  At N > 1 (configs[2]): the same 64 frames per GPU (weak scaling: 512 frames at N = 8), frames
+shard by rank, ONE RCCL all-gather of the per-rank unit embeddings, then every rank matches all gathered embeddings
+against the replicated 100k-entry gallery (so every rank holds the whole batch's result list).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -12,17 +13,23 @@ per-rank unit embeddings before the gallery match (weak scaling: 64 frames per G
 
 By default TWO batches are in flight per GPU (--streams 2): steps are issued round-robin to two independent
 library contexts on separate HIP streams, so the latency-bound kernels of one batch (IResNet at 64 faces has
-only 100-400 tiles per layer) overlap the other batch's.  Every step is still one full pass over one batch,
-all K steps complete inside the timed region; ms_per_step is elapsed / K.
+only 100-400 tiles per layer) overlap the other batch's.  Every step is still one full pass over one batch and all
+K steps complete inside a timed region.  The K-step region (barrier + synchronize on both sides, MAX over ranks) is
+repeated --repeats times (default 5) and the MEDIAN repeat is reported; `ms_per_step_repeats` lists them all.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with
-  roofline:     all MFMA conv launches of one step (the dominant kernel family conv_mfma_kernel<...>):
-                algorithmic FLOPs (2 x MACs of the true channel counts) / their summed device time,
-                timed with HIP events on the library's stream, against the 2.5 PFLOP/s dense fp16 peak
-  cpu_baseline: the oracle (fp32 torch-CPU restatement of the reference path) on this box's host cores
-                for a bounded sample of the same frames (N = 1 only).
+  roofline:     all MFMA conv launches of one step (the dominant kernel family): algorithmic FLOPs (2 x MACs of the true
+                channel counts) and algorithmic HBM bytes (every op's input + residual + output + weights as stored)
+                over their summed device time (HIP events on the library's stream); BOTH floors are reported per net
+                (hbm_floor_ms at 8 TB/s, mfma_floor_ms at the 2.5 PFLOP/s dense fp16 peak) and `bound` names the larger
+  cpu_baseline: the oracle (fp32 torch-CPU restatement of the reference path) on this box's host cores for a bounded
+                sample of the same frames (N = 1 only)
+  embed_cosine_delta_max / match_score_delta_max: device embeddings / gallery scores vs the oracle's on identical
+                landmarks (the second half of BASELINE.json's metric)
+  faces_per_s_F8, ms_per_step_h2d_included: side legs (F in {1, 8}; H2D reported separately).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -34,6 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec); ~6.3 TB/s is what a streaming copy achieves
+PROFILE_DIRS = ("r02", "r01")
 _T0 = time.time()
 
 
@@ -58,56 +67,6 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("FID_CPU_THREADS", "16"))))
 
 
-def build(ctx, batch, F, gallery_size, calib_frames):
-    from scrfd_arcface_facerecognition_amd import archs
-    from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
-    from scrfd_arcface_facerecognition_amd.pipeline import calibrate_detector_bias
-    det_net = archs.scrfd_10g((640, 640))
-    det_P = archs.synth_params(det_net, seed=0)
-    det_P, shift = calibrate_detector_bias(ctx, det_net, det_P, calib_frames, target=48)
-    rec_net = archs.iresnet50()
-    rec_P = archs.synth_params(rec_net, seed=0)
-    det = CompiledNet(ctx, det_net, det_P, max_batch=batch)
-    rec = CompiledNet(ctx, rec_net, rec_P, max_batch=batch * F)
-    g = np.random.default_rng(99).standard_normal((gallery_size, 512)).astype(np.float32)
-    gallery = Gallery(ctx, g)
-    return det_net, det_P, rec_net, rec_P, det, rec, gallery, g
-
-
-def mfma_roofline(pipe, frames_dev, batch, F):
-    """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs."""
-    from scrfd_arcface_facerecognition_amd.lower import OP_CONV, OP_STEM, OP_STEMFUSED
-    tot_ms, tot_flop, launches, per_net = 0.0, 0.0, 0, {}
-    for name, cn, imgs, n in (("scrfd_10g", pipe.det, frames_dev, batch), ("arcface_r50", pipe.rec, pipe.crops, batch * F)):
-        best = None
-        for _ in range(3):
-            ms = cn.run_profiled(imgs, n)
-            best = ms if best is None else np.minimum(best, ms)
-        t, fl, k = 0.0, 0.0, 0
-        by_name = {nd.name: nd for nd in cn.net.nodes}
-        for oi, names in enumerate(cn.low.op_nodes):
-            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED):
-                continue
-            macs = sum(node_macs(cn.net, by_name[nm]) for nm in names)
-            t += float(best[oi]); fl += 2.0 * macs * n; k += 1
-        per_net[name] = {"ms": round(t, 4), "tflops": round(fl / t / 1e9, 1), "launches": k,
-                         "net_ms_all_ops": round(float(best.sum()), 4)}
-        tot_ms += t; tot_flop += fl; launches += k
-    ach = tot_flop / tot_ms / 1e9
-    traffic = None       # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-        traffic = round(pmc["hbm_bytes_per_launch_corrected"])
-    except Exception:
-        pass
-    return {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
-            "kernel": "MFMA conv kernels of one step: conv_mfma_kernel<*> / conv_mfma_dma_kernel<*> / conv3x3_direct<*> / "
-                      "conv3x3_chunked<*> / conv3x3_pc<*> / conv3x3_pcr / scrfd_stem_fused<*> / stem_conv_mfma<*> (per layer the autotuner's pick)", "launches": launches,
-            "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2), "gflop_per_step": round(tot_flop / 1e9, 1),
-            "per_net": per_net}
-
-
 _shape_cache = {}
 
 
@@ -128,6 +87,77 @@ def node_macs(net, node):
     return 0
 
 
+def op_bytes(cn, oi, n):
+    """Algorithmic HBM bytes of one op on n images with layer-by-layer materialisation: its input (+ residual) read once,
+    its output written once, its weights read once -- tensors as stored (fp16 NHWC, channels padded to 32; fp32 heads;
+    u8 frames for the ops that read the image)."""
+    W_SRC, W_DST, W_RES, W_WBYTES = 1, 2, 3, 14          # word indices of an op record (csrc/net.h)
+    T_CP, T_H, T_W, T_DTYPE = 1, 2, 3, 4                 # ... of a tensor record
+    op, tens = cn.low.ops[oi], cn.low.tensors
+
+    def tb(tid):
+        t = tens[tid]
+        return int(t[T_H]) * int(t[T_W]) * int(t[T_CP]) * (4 if int(t[T_DTYPE]) == 1 else 2)
+    b = tb(int(op[W_DST])) * n + max(0, int(op[W_WBYTES]))
+    b += tb(int(op[W_SRC])) * n if int(op[W_SRC]) >= 0 else cn.in_hw[0] * cn.in_hw[1] * 3 * n
+    if int(op[W_RES]) >= 0:
+        b += tb(int(op[W_RES])) * n
+    return b
+
+
+def mfma_roofline(pipe, frames_dev, batch, F):
+    """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs and bytes."""
+    from scrfd_arcface_facerecognition_amd.lower import OP_CONV, OP_STEM, OP_STEMFUSED
+    tot_ms, tot_flop, tot_bytes, launches, per_net = 0.0, 0.0, 0.0, 0, {}
+    for name, cn, imgs, n in (("scrfd_10g", pipe.det, frames_dev, batch), ("arcface_r50", pipe.rec, pipe.crops, batch * F)):
+        best = None
+        for _ in range(3):
+            ms = cn.run_profiled(imgs, n)
+            best = ms if best is None else np.minimum(best, ms)
+        t, fl, by, k = 0.0, 0.0, 0.0, 0
+        by_name = {nd.name: nd for nd in cn.net.nodes}
+        for oi, names in enumerate(cn.low.op_nodes):
+            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED):
+                continue
+            macs = sum(node_macs(cn.net, by_name[nm]) for nm in names)
+            t += float(best[oi]); fl += 2.0 * macs * n; by += op_bytes(cn, oi, n); k += 1
+        hbm_floor, mfma_floor = by / (PEAK_HBM_GBS * 1e9) * 1e3, fl / (PEAK_FP16_TFLOPS * 1e12) * 1e3
+        per_net[name] = {"ms": round(t, 4), "tflops": round(fl / t / 1e9, 1), "gbs": round(by / t / 1e6, 1), "launches": k,
+                         "gflop": round(fl / 1e9, 1), "gbytes": round(by / 1e9, 3),
+                         "hbm_floor_ms": round(hbm_floor, 4), "mfma_floor_ms": round(mfma_floor, 4),
+                         "bound": "hbm" if hbm_floor > mfma_floor else "mfma",
+                         "frac_of_floor": round(max(hbm_floor, mfma_floor) / t, 4),
+                         "frac_mfma_peak": round(fl / t / 1e9 / PEAK_FP16_TFLOPS, 4), "frac_hbm_peak": round(by / t / 1e6 / PEAK_HBM_GBS, 4),
+                         "net_ms_all_ops": round(float(best.sum()), 4)}
+        tot_ms += t; tot_flop += fl; tot_bytes += by; launches += k
+    traffic, traffic_src = None, None   # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+    for d in PROFILE_DIRS:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")))
+            traffic = round(pmc["hbm_bytes_per_launch_corrected"])
+            traffic_src = f"profiles/{d}/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected separately)"
+            break
+        except Exception:
+            pass
+    hbm_floor, mfma_floor = tot_bytes / (PEAK_HBM_GBS * 1e9) * 1e3, tot_flop / (PEAK_FP16_TFLOPS * 1e12) * 1e3
+    tfl, gbs = tot_flop / tot_ms / 1e9, tot_bytes / tot_ms / 1e6
+    # the step's conv work taken as a whole: which floor is higher decides the bound the line quotes; both fractions are given
+    hbm_bound = hbm_floor > mfma_floor
+    return {"bound": "hbm" if hbm_bound else "mfma",
+            "achieved": round(gbs if hbm_bound else tfl, 1), "peak": PEAK_HBM_GBS if hbm_bound else PEAK_FP16_TFLOPS,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tfl / PEAK_FP16_TFLOPS), 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "achieved_tflops": round(tfl, 1), "frac_mfma_peak": round(tfl / PEAK_FP16_TFLOPS, 4),
+            "achieved_gbs_algorithmic": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
+            "hbm_floor_ms": round(hbm_floor, 4), "mfma_floor_ms": round(mfma_floor, 4), "conv_ms": round(tot_ms, 4),
+            "kernel": "MFMA conv kernels of one step (per layer the autotuner's pick among conv_mfma_kernel / conv_mfma_dma_kernel / "
+                      "conv3x3_direct / conv3x3_chunked / conv3x3_pc / conv3x3_pc2 / conv3x3_pcr / conv_s2 / scrfd_stem_fused / stem_conv_mfma)",
+            "launches": launches, "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2),
+            "gflop_per_step": round(tot_flop / 1e9, 1), "algorithmic_gbytes_per_step": round(tot_bytes / 1e9, 3),
+            "algorithmic_bytes_per_launch": round(tot_bytes / launches), "per_net": per_net}
+
+
 def cpu_baseline(frames, det_net, det_P, rec_net, rec_P, gallery, n_frames):
     """The oracle on the host cores, reference structure (frame by frame, face by face, python gallery loop)."""
     import torch
@@ -141,7 +171,7 @@ def cpu_baseline(frames, det_net, det_P, rec_net, rec_P, gallery, n_frames):
     while done < n_frames:
         faces += len(opipe.process_frame(frames[done % len(frames)], det_net, det_P, rec_net, rec_P, gallery, max_num=1))
         done += 1
-        if done % 16 == 0:
+        if done % 32 == 0:
             log(f"cpu_baseline: {done} frames, {time.perf_counter() - t0:.1f} s")
         if time.perf_counter() - t0 > 15:          # bounded sample: ~15 s of CPU work
             break
@@ -151,16 +181,48 @@ def cpu_baseline(frames, det_net, det_P, rec_net, rec_P, gallery, n_frames):
                       f"ArcFace-R50 fp32 torch-CPU oracle + python gallery loop (1k), {dt:.1f} s on {cores} threads"}
 
 
+def cosine_delta(pipe, frames, rec_net, rec_P, gal_host, thresh, n_check):
+    """metric's second half: device embeddings / match scores vs the fp32 oracle on the SAME landmarks (the detector's fp16
+    heads may rank another candidate first than fp32 heads would; decisions are compared on identical heads in tests/)."""
+    import torch
+    from oracle import match as omatch, pipeline as opipe
+    torch.set_num_threads(host_cores())
+    kps = pipe.post.kps.download()
+    emb = pipe.embeddings()
+    idx, score = pipe.idx.download(), pipe.score.download()
+    worst_e, worst_s, agree = 0.0, 0.0, 0
+    g_unit = gal_host / np.linalg.norm(gal_host, axis=1, keepdims=True)
+    for b in range(n_check):
+        ref, _ = opipe.embed(frames[b], kps[b, 0].reshape(5, 2), rec_net, rec_P)
+        e = emb[b * pipe.F]
+        worst_e = max(worst_e, 1.0 - float(ref @ e / np.linalg.norm(ref) / np.linalg.norm(e)))
+        sims = g_unit @ (ref / np.linalg.norm(ref))
+        j = int(idx[b * pipe.F])
+        oj, _ = omatch.match_batch(ref[None], gal_host, thresh)      # the reference's strict-'>' scan, vectorised
+        agree += int(int(oj[0]) == j)
+        worst_s = max(worst_s, abs(float(score[b * pipe.F]) - (float(sims[j]) if j >= 0 else 0.0)))
+    return {"embed_cosine_delta_max": round(worst_e, 6), "match_score_delta_max": round(worst_s, 6),
+            "match_index_agreement": f"{agree}/{n_check}", "cosine_delta_sample": f"{n_check} faces of the timed batch vs the fp32 oracle on identical landmarks"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated this often; the median is reported")
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--faces-per-frame", type=int, default=1)
-    ap.add_argument("--gallery", type=int, default=1000)
-    ap.add_argument("--cpu-frames", type=int, default=512, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--gallery", type=int, default=0, help="gallery entries (0 = 1000 at N = 1 [cfg 2], 100000 at N > 1 [cfg 3])")
+    ap.add_argument("--cpu-frames", type=int, default=512, help="frames of the CPU baseline sample (0 = skip; also skips the side legs)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the F = 8 and H2D-included side measurements")
+    ap.add_argument("--comm", choices=("torch", "native"), default=os.environ.get("FID_COMM", "torch"),
+                    help="who issues the all-gather at N > 1: torch.distributed (RCCL as backend nccl) or the C-ABI's fid_comm (RCCL)")
+    ap.add_argument("--match-scope", choices=("all", "own", "sharded"), default="all")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default=os.environ.get("FID_BENCH_BACKEND", "nccl"),
+                    help="gloo = REHEARSAL of the N > 1 code path with several ranks on ONE GPU (the gather is staged through host "
+                         "memory; RCCL refuses two ranks on one device); its numbers mean nothing")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FID_BENCH_STREAMS", "2")),
                     help="pipelines in flight per GPU: steps are issued round-robin to this many independent "
                          "contexts/HIP streams so that the small kernels of one batch overlap another batch's")
@@ -177,22 +239,69 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X; there is no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if args.backend == "gloo" else "cuda"
 
-    from scrfd_arcface_facerecognition_amd._lib import Context
-    from scrfd_arcface_facerecognition_amd.pipeline import FacePipeline, run_step_distributed
+    class StagedDist:
+        """rehearsal only: torch.distributed's surface with device buffers staged through host memory (gloo)"""
+        get_rank, get_world_size = staticmethod(dist.get_rank), staticmethod(dist.get_world_size)
+
+        @staticmethod
+        def all_gather_into_tensor(out, inp):
+            torch.cuda.current_stream().synchronize()
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
+
+    from scrfd_arcface_facerecognition_amd import archs
+    from scrfd_arcface_facerecognition_amd._lib import Context, check
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
+    from scrfd_arcface_facerecognition_amd.pipeline import (Communicator, FacePipeline, build_targets_from_images,
+                                                            calibrate_detector_bias, run_step_distributed, shard_range)
     stream = torch.cuda.Stream()
     ctx = Context(local_rank, stream.cuda_stream)
     B, F = args.batch, args.faces_per_frame
+    G = args.gallery or (1000 if world == 1 else 100_000)
+    thresh = 0.4
     calib = np.random.default_rng(1234).integers(0, 256, (8, 640, 640, 3), dtype=np.uint8)   # same on every rank
     frames = np.random.default_rng(1234 + rank).integers(0, 256, (B, 640, 640, 3), dtype=np.uint8)
     log("building nets (synthetic weights, detector bias calibration)")
-    det_net, det_P, rec_net, rec_P, det, rec, gallery, gal_host = build(ctx, B, F, args.gallery, calib)
-    log("nets resident")
+    det_net = archs.scrfd_10g((640, 640))
+    det_P, _ = calibrate_detector_bias(ctx, det_net, archs.synth_params(det_net, seed=0), calib, target=48)
+    rec_net = archs.iresnet50()
+    rec_P = archs.synth_params(rec_net, seed=0)
+    det = CompiledNet(ctx, det_net, det_P, max_batch=B)
+    rec = CompiledNet(ctx, rec_net, rec_P, max_batch=B * F)
+
+    # gallery (same on every rank): the first 8 entries come from the reference's own gallery construction (build_targets,
+    # main.py:78-105) run through the device path on the calibration frames; the rest are random 512-d vectors
+    gal_host = np.random.default_rng(99).standard_normal((G, 512)).astype(np.float32)
+    names = [str(i) for i in range(G)]
+
+    from models import SCRFD, ArcFace                     # the reference's import path (main.py:11)
+    from scrfd_arcface_facerecognition_amd.session import HipSession
+    bt_det = SCRFD(None, input_size=(640, 640), conf_thres=0.5, max_batch=8,
+                   session=HipSession(None, ctx=ctx, net=det_net, params=det_P, max_batch=8))
+    bt_rec = ArcFace(session=HipSession(None, ctx=ctx, net=rec_net, params=rec_P, max_batch=8))
+    targets = build_targets_from_images(bt_det, bt_rec, list(calib), [f"calib{i}" for i in range(len(calib))])
+    for cn_ in list(bt_det.session._compiled.values()) + list(bt_rec.session._compiled.values()):
+        cn_.close()                                       # start-up only: free the gallery-construction nets
+    for i, (e, nm) in enumerate(targets):
+        gal_host[i], names[i] = e, nm
+    log(f"gallery: {G} entries, {len(targets)} of them built by build_targets from the calibration frames")
+
+    sharded = args.match_scope == "sharded" and world > 1
+    g_lo, g_hi = shard_range(G, world, rank) if sharded else (0, G)
+    gallery = Gallery(ctx, gal_host[g_lo:g_hi], names[g_lo:g_hi])
+    log("nets + gallery resident")
 
     class Lane:
         """one independent pipeline: its own HIP stream / library context, nets, buffers"""
@@ -208,12 +317,26 @@ def main():
             ln.ctx = Context(local_rank, ln.stream.cuda_stream)
             ln.det = CompiledNet(ln.ctx, det_net, det_P, max_batch=B)
             ln.rec = CompiledNet(ln.ctx, rec_net, rec_P, max_batch=B * F)
-            ln.gallery = Gallery(ln.ctx, gal_host)
+            ln.gallery = Gallery(ln.ctx, gal_host[g_lo:g_hi], names[g_lo:g_hi])
+        n = B * F
         with torch.cuda.stream(ln.stream):
-            ln.q_local = torch.empty((B * F, 512), dtype=torch.float16, device="cuda")
-            ln.q_all = torch.empty((world * B * F, 512), dtype=torch.float16, device="cuda") if world > 1 else None
+            ln.q_local = torch.empty((n, 512), dtype=torch.float16, device="cuda")
             ln.pipe = FacePipeline(ln.ctx, ln.det, ln.rec, batch=B, faces_per_frame=F, q_buffer=ln.q_local)
             ln.frames_dev = ln.ctx.to_device(frames)     # resident in HBM before the timed region
+            if world > 1:
+                ln.q_all = torch.empty((world * n, 512), dtype=torch.float16, device="cuda")
+                ln.idx_all = torch.empty((world * n,), dtype=torch.int32, device="cuda")
+                ln.score_all = torch.empty((world * n,), dtype=torch.float32, device="cuda")
+                ln.keys_local = torch.empty((world * n,), dtype=torch.int64, device="cuda")
+                ln.keys_all = torch.empty((world * world * n,), dtype=torch.int64, device="cuda")
+                if args.comm == "native":
+                    def exchange(ident):
+                        box = [ident]
+                        dist.broadcast_object_list(box, src=0)
+                        return box[0]
+                    ln.dist = Communicator(ln.ctx, world, rank, exchange)
+                else:
+                    ln.dist = StagedDist if args.backend == "gloo" else dist
         lanes.append(ln)
     pipe, frames_dev = lanes[0].pipe, lanes[0].frames_dev
 
@@ -221,65 +344,141 @@ def main():
         ln = lanes[i % len(lanes)]
         with torch.cuda.stream(ln.stream):
             if world > 1:
-                run_step_distributed(ln.pipe, ln.frames_dev, 640, 640, ln.gallery, 0.4, ln.q_local, ln.q_all, dist)
+                run_step_distributed(ln.pipe, ln.frames_dev, 640, 640, ln.gallery, thresh, ln.q_local, ln.q_all, ln.dist,
+                                     idx_all=ln.idx_all, score_all=ln.score_all, match_scope=args.match_scope,
+                                     keys_local=ln.keys_local, keys_all=ln.keys_all, gallery_first_row=g_lo, gallery_total=G)
             else:
-                ln.pipe.run_step(ln.frames_dev, 640, 640, ln.gallery, 0.4)
+                ln.pipe.run_step(ln.frames_dev, 640, 640, ln.gallery, thresh)
 
-    if True:
-        for i in range(len(lanes)):              # every lane tunes its kernels alone on the GPU
-            step(i)
-            torch.cuda.synchronize()
-        for i in range(args.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        log("warm-up done")
+    def timed_region(fn, k):
+        """exactly k steps between (barrier + synchronize) pairs; MAX over ranks"""
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
+        for i in range(k):
+            fn(i)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
-
-        pipe.post.check()
-        counts = pipe.post.counts.download()
-        faces_step = int(np.minimum(counts, F).sum())
+        el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-            fc = torch.tensor([faces_step], dtype=torch.int64, device="cuda")
-            dist.all_reduce(fc, op=dist.ReduceOp.SUM)
-            faces_total_step = int(fc.item())
-        else:
-            faces_total_step = faces_step
+            el = float(t.item())
+        return el
 
-        out = None
-        if rank == 0:
-            value = faces_total_step * args.steps / elapsed
-            out = {
-                "metric": "faces/sec end-to-end (det+align+embed+match)", "value": round(value, 2), "unit": "faces/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-                "config": {"workload": "SCRFD-10G + ArcFace-R50, 64 synthetic 640x640 frames per GPU per step, "
-                                       f"F={F} face/frame (max_num), {args.gallery}-entry gallery, random-init weights (seed 0)",
-                           "frames_per_gpu": B, "faces_per_step": faces_total_step, "gallery": args.gallery,
-                           "parallelism": (f"frames sharded over {world} GPU(s), 1 all-gather of embeddings" if world > 1 else "1 GPU")
-                                          + (f", {len(lanes)} batches in flight per GPU on separate HIP streams" if len(lanes) > 1 else "")},
-            }
-            if not args.no_roofline:
-                log("roofline: per-op HIP-event timing")
-                out["roofline"] = mfma_roofline(pipe, frames_dev, B, F)
-        if rank == 0 and world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(frames, det_net, det_P, rec_net, rec_P, gal_host, args.cpu_frames)
-        if rank == 0:
-            print(json.dumps(out), flush=True)
+    for i in range(len(lanes)):              # every lane tunes its kernels alone on the GPU
+        step(i)
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    log("warm-up done")
+    repeats = [timed_region(step, args.steps) for _ in range(max(1, args.repeats))]
+    elapsed = float(np.median(repeats))
+    log(f"timed regions done: {[round(r / args.steps * 1e3, 3) for r in repeats]} ms/step, median {elapsed / args.steps * 1e3:.3f}")
+
+    pipe.post.check()
+    counts = pipe.post.counts.download()
+    faces_step = int(np.minimum(counts, F).sum())
+    if world > 1:
+        fc = torch.tensor([faces_step], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(fc, op=dist.ReduceOp.SUM)
+        faces_total_step = int(fc.item())
+        # the gathered result list must cover every rank's faces (scope "all"/"sharded": every rank holds the whole batch)
+        if args.match_scope != "own":
+            assert lanes[0].idx_all.shape[0] == world * B * F
+    else:
+        faces_total_step = faces_step
+
+    out = None
+    if rank == 0:
+        value = faces_total_step * args.steps / elapsed
+        par = "1 GPU"
+        if world > 1:
+            par = (f"frames sharded over {world} GPUs (one process each), 1 RCCL all-gather of the unit embeddings issued by "
+                   f"{'the C-ABI communicator (fid_allgather)' if args.comm == 'native' else 'torch.distributed (backend nccl = RCCL)'}, "
+                   f"match scope '{args.match_scope}'"
+                   + (" (gallery row-sharded, second 8-byte-per-query key all-gather)" if sharded else " (gallery replicated, every rank matches all gathered embeddings)"))
+        out = {
+            "metric": "faces/sec end-to-end (det+align+embed+match)", "value": round(value, 2), "unit": "faces/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic" if args.backend == "nccl" else "REHEARSAL (gloo, ranks share one GPU): not a measurement",
+            "config": {"workload": ("BASELINE configs[1]: " if world == 1 else "BASELINE configs[2] (weak-scaled: 64 frames per GPU): ")
+                                   + f"SCRFD-10G + ArcFace-R50, {B} synthetic 640x640 frames per GPU per step, "
+                                   f"F={F} face/frame (max_num), {G}-entry gallery, random-init weights (seed 0)",
+                       "frames_per_gpu": B, "faces_per_step": faces_total_step, "gallery": G,
+                       "parallelism": par + (f", {len(lanes)} batches in flight per GPU on separate HIP streams" if len(lanes) > 1 else "")},
+            "repeats": len(repeats), "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in repeats],
+            "ms_per_step_min": round(min(repeats) / args.steps * 1e3, 4),
+        }
+        if not args.no_roofline:
+            log("roofline: per-op HIP-event timing")
+            out["roofline"] = mfma_roofline(pipe, frames_dev, B, F)
+    side = rank == 0 and world == 1 and args.cpu_frames > 0
+    if side:
+        # the batch the roofline leg left in the pipeline is `frames`; re-run one step so idx/score/kps belong to it
+        pipe.run_step(frames_dev, 640, 640, gallery, thresh)
+        ctx.sync()
+        log("cosine delta vs the oracle")
+        out.update(cosine_delta(pipe, frames, rec_net, rec_P, gal_host, thresh, n_check=min(16, B)))
+    if side and not args.no_side_legs:
+        torch.cuda.synchronize()
+        # ---- side leg 1: H2D included.  Per lane two device frame buffers and one pinned host batch; the upload of the next
+        # batch runs on the lane's copy stream beside the current step (fid_upload_async_slot), no host synchronisation.
+        log("side leg: H2D-included steps")
+        from scrfd_arcface_facerecognition_amd.video import _Pinned
+        for ln in lanes:
+            ln.pinned = _Pinned(ln.ctx, frames.shape, np.uint8)
+            ln.pinned.array[:] = frames
+            ln.dev2 = [ln.frames_dev, ln.ctx.to_device(frames)]
+            ln.k = 0
+
+        def step_h2d(i):
+            ln = lanes[i % len(lanes)]
+            k = ln.k
+            ln.k ^= 1
+            with torch.cuda.stream(ln.stream):
+                check(ln.ctx.lib.fid_upload_async_slot(ln.ctx.handle, k, C.c_void_p(ln.dev2[k].ptr), C.c_void_p(ln.pinned.ptr), ln.pinned.nbytes))
+                check(ln.ctx.lib.fid_upload_wait_slot(ln.ctx.handle, k))
+                ln.pipe.run_step(ln.dev2[k], 640, 640, ln.gallery, thresh)
+                check(ln.ctx.lib.fid_upload_release(ln.ctx.handle, k))
+        for i in range(4):
+            step_h2d(i)
+        h2d = [timed_region(step_h2d, args.steps) for _ in range(3)]
+        out["ms_per_step_h2d_included"] = round(float(np.median(h2d)) / args.steps * 1e3, 4)
+        out["faces_per_s_h2d_included"] = round(faces_total_step * args.steps / float(np.median(h2d)), 2)
+        out["h2d_note"] = (f"{frames.nbytes / 1e6:.1f} MB of frames per step uploaded from pinned host memory on a separate HIP stream, "
+                           "double-buffered per lane (fid_upload_async_slot); never part of `value`")
+        # ---- side leg 2: F = 8 faces per frame (SURVEY.md 8d reports F in {1, 8}); one lane pair, recogniser at 512 faces
+        log("side leg: F = 8")
+        F8 = 8
+        for ln in lanes:
+            ln.rec8 = CompiledNet(ln.ctx, rec_net, rec_P, max_batch=B * F8)
+            with torch.cuda.stream(ln.stream):
+                ln.pipe8 = FacePipeline(ln.ctx, ln.det, ln.rec8, batch=B, faces_per_frame=F8)
+
+        def step8(i):
+            ln = lanes[i % len(lanes)]
+            with torch.cuda.stream(ln.stream):
+                ln.pipe8.run_step(ln.frames_dev, 640, 640, ln.gallery, thresh)
+        for i in range(len(lanes)):
+            step8(i)
+            torch.cuda.synchronize()
+        step8(0); step8(1)
+        f8 = [timed_region(step8, 10) for _ in range(3)]
+        lanes[0].pipe8.post.check()
+        faces8 = int(np.minimum(lanes[0].pipe8.post.counts.download(), F8).sum())
+        out["faces_per_s_F8"] = round(faces8 * 10 / float(np.median(f8)), 2)
+        out["ms_per_step_F8"] = round(float(np.median(f8)) / 10 * 1e3, 4)
+        out["faces_per_step_F8"] = faces8
+    if side:
+        out["cpu_baseline"] = cpu_baseline(frames, det_net, det_P, rec_net, rec_P, gal_host, args.cpu_frames)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -18,7 +18,8 @@ __all__ = ["SCRFD"]
 
 class SCRFD:
     def __init__(self, model_path: str, input_size: Tuple[int] = (640, 640), conf_thres: float = 0.5,
-                 iou_thres: float = 0.4, *, device: int = 0, ctx=None, max_batch: int = 8, max_det: int = 512) -> None:
+                 iou_thres: float = 0.4, *, device: int = 0, ctx=None, max_batch: int = 8, max_det: int = 512,
+                 session=None) -> None:
         self.input_size = input_size
         self.conf_thres = conf_thres
         self.iou_thres = iou_thres
@@ -32,12 +33,14 @@ class SCRFD:
         self.center_cache = {}
         self._device, self._ctx, self._max_batch, self._max_det = device, ctx, int(max_batch), int(max_det)
         self._post = None
+        self._session = session        # keyword-only extension: a ready HipSession (like ArcFace(session=...), arcface.py:11-21)
         self._initialize_model(model_path=model_path)
 
     def _initialize_model(self, model_path: str):
         try:
-            self.session = HipSession(model_path, ctx=self._ctx, device=self._device,
-                                      input_hw=(self.input_size[1], self.input_size[0]), max_batch=self._max_batch)
+            self.session = self._session or HipSession(model_path, ctx=self._ctx, device=self._device,
+                                                       input_hw=(self.input_size[1], self.input_size[0]),
+                                                       max_batch=self._max_batch)
             self.output_names = [x.name for x in self.session.get_outputs()]
             self.input_names = [x.name for x in self.session.get_inputs()]
         except Exception as e:                       # reference scrfd.py:66-68
