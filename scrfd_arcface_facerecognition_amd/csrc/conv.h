@@ -15,6 +15,7 @@ enum : int {
 struct ConvArgs {
     const void *in;     // fp16 [B, H, W, Cin_p]
     const void *w;      // fp16 [w_rows][T][Cin_p]   (T = kh*kw taps, tap-major then channel)
+    const void *w_alt;  // the same weights in the packing plan_alt_kind(plan) names (repack.hip), or NULL
     const float *bias;  // fp32 [ncls][Cout_p]  (ncls = 9 with CF_BORDER else 1), may be NULL
     const float *slope; // fp32 [Cout_p] PReLU slopes (ACT_PRELU)
     const void *res;    // fp16 residual [B, res_H, res_W, res_Cp] or NULL
@@ -36,7 +37,7 @@ struct ConvArgs {
 // must hold ksplit*M*Cout_p floats when the plan splits K (query with conv_plan first).
 struct ConvPlan {
     int bm, bn, bk, ksplit;
-    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr, 8 = conv_pc2
+    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr, 8 = conv_pc2, 9 = conv_wr
     int ns;    // ring slots (gen 2); 5 = 4 slots + fragment prefetch across K-steps
     size_t partial_bytes;
 };
@@ -46,6 +47,10 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split);
 #include <vector>
 std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split);
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan);
+// alternate weight packing a plan's kernel wants in ConvArgs::w_alt (0 = none); repack.hip builds it
+int plan_alt_kind(const ConvPlan &plan);
+size_t repack_bytes(int kind, int Cout_p, int Cin_p);
+int repack_weights(fid_ctx *ctx, int kind, const void *src, void *dst, int Cout_p, int Cin_p);
 
 // conv_direct.hip: 3x3/s1 conv with LDS-resident weights + haloed patches (<= 64 channels in and out)
 bool conv_direct_applicable(const ConvArgs &a);
@@ -69,6 +74,11 @@ bool conv_pc2_applicable(const ConvArgs &a);
 int conv_pc2_launch(fid_ctx *ctx, const ConvArgs &a);
 bool conv_pcr_applicable(const ConvArgs &a);
 int conv_pcr_launch(fid_ctx *ctx, const ConvArgs &a);
+
+// conv_wr.hip (generation 9): weights in registers, waves split by cout, a pair of tiles x 128 couts per item; needs w_alt (kind 2)
+bool conv_wr_applicable(const ConvArgs &a);
+bool conv_wr_resident_ok(const ConvArgs &a);
+int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident);
 
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,

@@ -824,6 +824,13 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
     }
     if (conv_pcr_applicable(a)) { ConvPlan d{}; d.gen = 7; d.ksplit = 1; d.bm = 256; d.bn = 64; d.bk = 32; out.push_back(d); }
     if (conv_pc2_applicable(a)) { ConvPlan d{}; d.gen = 8; d.ksplit = 1; d.bm = 512; d.bn = 64; d.bk = 32; out.push_back(d); }
+    if (conv_wr_applicable(a)) {
+        ConvPlan d{};
+        d.gen = 9; d.ksplit = 1; d.bk = 32;
+        d.bm = 512; d.bn = 128; out.push_back(d);      // a pair of tiles x 128 couts
+        d.bm = 256; d.bn = 64; out.push_back(d);       // one tile x 64 couts (few tiles: more items)
+        if (conv_wr_resident_ok(a)) { d.bm = 256; d.bn = a.Cout_p; d.ns = 1; out.push_back(d); }   // the layer's weights resident in registers
+    }
     if (conv_pc_applicable(a)) {
         ConvPlan d{};
         d.gen = 5; d.ksplit = 1; d.bm = 256; d.bk = 32;
@@ -886,6 +893,13 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
     return out;
 }
 
+int plan_alt_kind(const ConvPlan &plan) {
+    static const bool pc2_packed = getenv("FID_PC2_PLAIN") == nullptr;
+    if (plan.gen == 8) return pc2_packed ? 1 : 0;
+    if (plan.gen == 9) return 2;
+    return 0;
+}
+
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 0) return conv_direct_launch(ctx, a);
     if (plan.gen == 3) return conv_chunked_launch(ctx, a, plan.bn);
@@ -893,6 +907,7 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 5) return conv_pc_launch(ctx, a, plan.bn, plan.ns);
     if (plan.gen == 7) return conv_pcr_launch(ctx, a);
     if (plan.gen == 8) return conv_pc2_launch(ctx, a);
+    if (plan.gen == 9) return conv_wr_launch(ctx, a, plan.bm / 256, plan.bn, plan.ns);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);
     FID_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 4 == 0, "conv: channel padding (Cin_p=%d Cout_p=%d)", a.Cin_p, a.Cout_p);

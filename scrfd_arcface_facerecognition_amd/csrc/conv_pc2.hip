@@ -53,6 +53,7 @@ struct PC2Args {
     int tiles_x, tiles_per_img, n_tiles, n_cblk, n_items, n_chunks;
     FastDiv d_cblk, d_tpi, d_tx;
     unsigned in_bytes, w_bytes;
+    int w_packed;   // a.w is repack.hip's kind-1 image: every 1-KB weight piece contiguous
 };
 
 template <int N>
@@ -98,6 +99,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc2(const P
             const int row = (pw + N_PROD * k) * 16 + (lane >> 2);
             const int t = row / CB, co = row - t * CB;
             w_off[k] = ((co * 9 + t) * a.Cin_p + ((lane & 3) ^ swz64(row)) * 8) * 2;
+            if (a.w_packed) w_off[k] = (pw + N_PROD * k) * 1024 + lane * 16;
         }
         int p_pk[MAX_P];                                       // py | px << 8 | channel offset << 16 (py = 255: padding row) of my k-th patch block
 #pragma unroll
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc2(const P
         auto cursor_decode = [&](Cursor &c) {
             int pair, cb;
             decode_item(c.item, pair, cb);
-            c.w_base = cb * CB * 9 * a.Cin_p * 2;
+            c.w_base = cb * CB * 9 * a.Cin_p * 2;       // also the packed image's block offset: n_chunks * W_BYTES per cout block
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int t = pair * 2 + h;
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc2(const P
             }
         };
         auto issue_weights = [&](const Cursor &c, int slot) {  // exactly MAX_W instructions
-            const int ubase = c.w_base + c.ck * CK * 2;
+            const int ubase = c.w_base + c.ck * (a.w_packed ? W_BYTES : CK * 2);
             char *dst = sWr + slot * W_BYTES;
 #pragma unroll
             for (int k = 0; k < MAX_W; k++)
@@ -423,7 +425,7 @@ bool conv_pc2_applicable(const ConvArgs &a) {
 
 int conv_pc2_launch(fid_ctx *ctx, const ConvArgs &c) {
     PC2Args a{};
-    a.in = c.in; a.w = c.w; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
+    a.in = c.in; a.w = c.w_alt ? c.w_alt : c.w; a.w_packed = c.w_alt != nullptr; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
     a.act = c.act; a.flags = c.flags; a.res_Cp = c.res_Cp;
     const int B = c.M / (c.Ho * c.Wo);

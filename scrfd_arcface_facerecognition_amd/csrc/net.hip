@@ -34,6 +34,8 @@ struct fid_net {
     // two boxes run the SAME kernels and fp32 summation orders and return bit-identical heads / embeddings
     unsigned long long table_hash = 0;
     std::string device_key, plan_path;
+    // repacked weight copies per (op, kind), built on first use (repack.hip); freed with the net
+    std::map<std::pair<int, int>, void *> alt_w;
 };
 
 namespace fid {
@@ -316,6 +318,23 @@ int plan_load(fid_net *net, const char *path, int *n_loaded) {
     return FID_OK;
 }
 
+// ConvArgs::w_alt for `plan` (built on the context's stream the first time an op needs that packing)
+int set_alt_weights(fid_ctx *ctx, fid_net *net, int oi, ConvArgs &a, const ConvPlan &plan) {
+    const int kind = plan_alt_kind(plan);
+    a.w_alt = nullptr;
+    if (kind == 0) return FID_OK;
+    auto key = std::make_pair(oi, kind);
+    auto it = net->alt_w.find(key);
+    if (it == net->alt_w.end()) {
+        void *p = nullptr;
+        FID_HIP(hipMalloc(&p, repack_bytes(kind, a.Cout_p, a.Cin_p) + 256));
+        FID_TRY(repack_weights(ctx, kind, a.w, p, a.Cout_p, a.Cin_p));
+        it = net->alt_w.emplace(key, p).first;
+    }
+    a.w_alt = it->second;
+    return FID_OK;
+}
+
 // one op on images [first, first + batch) of the resident batch
 int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first, int batch, void *partial_ws) {
     const int32_t *op = &net->ops[(size_t)oi * FID_OP_WORDS];
@@ -397,7 +416,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 if (const char *fn = getenv("FID_FORCE_NS")) {       // tests: one ring variant of generation 2 / 5
                     std::vector<ConvPlan> only;
                     for (const ConvPlan &c : cands)
-                        if ((c.gen == 2 || c.gen == 5) && c.ns == atoi(fn)) only.push_back(c);
+                        if (((c.gen == 2 || c.gen == 5) && c.ns == atoi(fn)) || (c.gen == 9 && (c.ns ? 3 : c.bm / 256) == atoi(fn))) only.push_back(c);
                     if (!only.empty()) cands = only;
                 }
                 const float pc2_bias = getenv("FID_PC2_BIAS") ? (float)atof(getenv("FID_PC2_BIAS")) : 1.f;
@@ -411,6 +430,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                     if (c.partial_bytes > net->partial_cap) continue;
                     float tmin = 1e30f;
                     for (int rep = 0; rep < 5; rep++) {
+                        FID_TRY(set_alt_weights(ctx, net, oi, a, c));
                         FID_HIP(hipEventRecord(e0, ctx->stream));
                         FID_TRY(conv_launch(ctx, a, c));
                         FID_HIP(hipEventRecord(e1, ctx->stream));
@@ -441,6 +461,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 plan = conv_direct_applicable(a) ? ConvPlan{} : conv_plan(a, ctx->num_cus, partial_ws != nullptr);
                 if (conv_direct_applicable(a)) { plan.gen = 0; plan.ksplit = 1; }
             }
+            FID_TRY(set_alt_weights(ctx, net, oi, a, plan));
             FID_TRY(conv_launch(ctx, a, plan));
             break;
         }
@@ -712,6 +733,8 @@ int fid_net_destroy(fid_ctx *ctx, fid_net *net) {
     for (void *p : net->slots)
         if (p) (void)hipFree(p);
     if (net->blob) (void)hipFree(net->blob);
+    for (auto &kv : net->alt_w)
+        if (kv.second) (void)hipFree(kv.second);
     for (auto &kv : net->replays)
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     if (net->prof_events) {

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarise the two rocprofv3 PMC passes of tools/pmc_mfma.sh per kernel.
+
+  mfma_util  = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)      share of the CUs' busy cycles with a matrix pipe busy
+  mfma_chip  = SQ_VALU_MFMA_BUSY_CYCLES / (4 x 256 CUs x GRBM_GUI_ACTIVE / 8)  the same against the whole chip for the kernel's duration
+               (GRBM_GUI_ACTIVE is summed over the 8 XCDs: MI355X_MICROARCH.md, DVFS give-back)
+  wait / issue-stall / active = SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES (disjoint shares of a wave's life)
+Counters are hardware sums over all dispatches of a kernel name in the run (autotuning launches included)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def load(run_dir):
+    files = glob.glob(os.path.join(run_dir, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        sys.exit(f"no counter_collection.csv under {run_dir}")
+    acc = defaultdict(lambda: defaultdict(float))
+    n = defaultdict(set)
+    with open(files[0]) as f:
+        for row in csv.DictReader(f):
+            k = row["Kernel_Name"]
+            k = k.replace("(anonymous namespace)::", "").replace("void ", "").replace("fid::", "").split("(")[0]
+            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            n[k].add(row["Dispatch_Id"])
+    return acc, {k: len(v) for k, v in n.items()}
+
+
+def main():
+    out = sys.argv[1]
+    a, na = load(os.path.join(out, "a"))
+    b, _ = load(os.path.join(out, "b"))
+    rows = []
+    for k, c in a.items():
+        if c.get("SQ_WAVE_CYCLES", 0) <= 0:
+            continue
+        busy_cu = c.get("SQ_BUSY_CU_CYCLES", 0)
+        gui = c.get("GRBM_GUI_ACTIVE", 0)
+        mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+        wc = c["SQ_WAVE_CYCLES"]
+        d = b.get(k, {})
+        rows.append((gui, k, na[k], mf / (4 * busy_cu) if busy_cu else 0, mf / (4 * 256 * gui / 8) if gui else 0,
+                     c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc, c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                     d.get("SQ_WAIT_INST_LDS", 0) / wc, d.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, d.get("SQ_LDS_IDX_ACTIVE", 0)),
+                     c.get("SQ_INSTS_MFMA", 0)))
+    rows.sort(reverse=True)
+    tot = sum(r[0] for r in rows)
+    print(f"{'kernel':60s} {'launches':>8s} {'time%':>6s} {'mfma_util':>9s} {'mfma_chip':>9s} {'wait':>6s} {'istall':>6s} {'active':>6s} {'lds_st':>6s} {'bankcf':>6s} {'mfma_insts':>12s}")
+    for gui, k, n, mu, mc, w, ws, ac, wl, bc, ni in rows[:30]:
+        print(f"{k[:60]:60s} {n:8d} {100 * gui / tot:6.1f} {100 * mu:9.1f} {100 * mc:9.1f} {100 * w:6.1f} {100 * ws:6.1f} {100 * ac:6.1f} {100 * wl:6.1f} {100 * bc:6.1f} {ni:12.0f}")
+
+
+if __name__ == "__main__":
+    main()
