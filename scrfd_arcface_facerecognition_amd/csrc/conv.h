@@ -37,7 +37,7 @@ struct ConvArgs {
 // must hold ksplit*M*Cout_p floats when the plan splits K (query with conv_plan first).
 struct ConvPlan {
     int bm, bn, bk, ksplit;
-    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr, 8 = conv_pc2, 9 = conv_wr
+    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr, 8 = conv_pc2, 9 = conv_wr, 10 = conv_s2
     int ns;    // ring slots (gen 2); 5 = 4 slots + fragment prefetch across K-steps
     size_t partial_bytes;
 };
@@ -79,6 +79,10 @@ int conv_pcr_launch(fid_ctx *ctx, const ConvArgs &a);
 bool conv_wr_applicable(const ConvArgs &a);
 bool conv_wr_resident_ok(const ConvArgs &a);
 int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident);
+
+// conv_s2.hip (generation 10): 3x3 / stride 2 with parity-plane patches and resident weights (64 / 96 input channels); needs w_alt (kind 2)
+bool conv_s2_applicable(const ConvArgs &a);
+int conv_s2_launch(fid_ctx *ctx, const ConvArgs &a);
 
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,

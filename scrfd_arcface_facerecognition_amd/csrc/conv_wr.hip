@@ -173,15 +173,26 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     f32x4 acc[NT][TH];
 
     // one tap column of a step: PH pixel-fragment rows x (up to) 3 taps x NT tiles
-    constexpr int PD = NT == 1 ? (NCH == 3 ? 2 : 4) : 1;                         // pixel fragments read ahead (a fragment feeds <= 3*NT MFMAs = 48*NT cycles; an LDS read takes > 100)
+    constexpr int PD = NT == 1 ? (NCH == 3 ? 2 : 4) : 2;                         // pixel fragments read ahead (a fragment feeds <= 3*NT MFMAs = 48*NT cycles; an LDS read takes > 100)
     auto compute_col = [&](const char *sP, int dx_, auto wb_tag) {
         constexpr int WB = decltype(wb_tag)::value * 9;
+        // the eight per-lane fragment bases of this slot, made opaque: every read is then "base register + immediate" -- left to
+        // itself the compiler hoists one address register PER READ out of the step loop (54 VGPRs of loop-invariant addresses)
+        int pb[2][4];
+        const int slot_off = (int)(sP - smem);
+#pragma unroll
+        for (int par = 0; par < 2; par++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                pb[par][c] = pbase[par][c] + slot_off;
+                asm volatile("" : "+v"(pb[par][c]));
+            }
         half8 pq[PD + 1][NT];
         auto load_p = [&](int q, int set) {                     // q = dx * PH + patch row
             const int K = (q % PH) * PW + q / PH;               // lin = K + frow
-            const int off = pbase[K & 1][(K >> 1) & 3] + K * 64;
 #pragma unroll
-            for (int t = 0; t < NT; t++) pq[set][t] = *(const half8 *)(sP + t * P_BYTES + ((a.ablate & 16) ? (off & 15) : off));
+            for (int t = 0; t < NT; t++)
+                pq[set][t] = *(const half8 *)(smem + ((a.ablate & 16) ? (pb[K & 1][(K >> 1) & 3] & 15) : pb[K & 1][(K >> 1) & 3] + (K * 64 + t * P_BYTES)));
         };
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) {
@@ -215,7 +226,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     constexpr int HR = NCH > 0 ? TH : ((TH / 2) < (SLOT / (16 * ROWB)) ? (TH / 2) : (SLOT / (16 * ROWB)));
     constexpr int NPASS = (TH + HR - 1) / HR;
     constexpr int ST_I = (HR * 16 * CPX + NW * 64 - 1) / (NW * 64), EPI_ST = NPASS * NT * ST_I;   // write-out instructions per wave and pass / item
-    constexpr int RG = ((NCH == 3 || (TH == 16 && NT == 2)) && HR > 4) ? 4 : HR;   // residual rows in registers at a time (variants short of registers: 4)
+    constexpr int RG = NCH > 0 ? 2 : (((TH == 16 && NT == 2) && HR > 4) ? 4 : HR);   // residual rows in registers at a time (resident variant: they come from LDS, just in time)
     constexpr int EPI_RL = NT * NPASS * ((HR + RG - 1) / RG) * RG;                   // residual loads per item (rows past a pass / the tile: out of bounds)
     static_assert(HR >= 1 && (NCH > 0 || HR * 16 * ROWB <= SLOT), "staging area");
     // resident variant: one cout block, so the bias row / PReLU slopes of a lane never change -- fetched once, not per tile; and the
@@ -520,7 +531,8 @@ static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
         FID_HIP(hipFuncSetAttribute((const void *)conv3x3_wr<TH, NT, NW, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    const int wg_per_cu = std::max(1, std::min(16 / NW, (160 * 1024) / LDS));     // <= 256 VGPRs per wave: 16 waves per CU
+    // waves per CU by registers: > 168 VGPRs -> two per SIMD (8 per CU); the one-tile streaming variant stays below 168 -> three per SIMD
+    const int wg_per_cu = std::max(1, std::min((NT == 1 && NCH == 0 ? 12 : 8) / NW, (160 * 1024) / LDS));
     const int grid = std::min(a.n_items, ctx->num_cus * wg_per_cu);
     hipLaunchKernelGGL((conv3x3_wr<TH, NT, NW, NCH>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
     FID_HIP(hipGetLastError());

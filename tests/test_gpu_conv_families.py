@@ -81,3 +81,35 @@ def test_dethead_family(ctx, monkeypatch, gen, hw, cin, batch):
     assert np.abs(fused[..., 0:2].reshape(batch, -1, 1) - sc).max() < 2e-3
     assert np.abs(fused[..., 2:10].reshape(batch, -1, 4) - bb).max() < 2e-2
     assert np.abs(fused[..., 10:30].reshape(batch, -1, 10) - kp).max() < 2e-2
+
+
+# stride-2 3x3 convs (generation 10: parity-plane patches, resident weights) against the implicit-GEMM families and the oracle:
+# 64 / 96-channel inputs, 64 / 96 / 128 couts, with and without a residual (the IResNet block's downsample branch), odd maps
+@pytest.mark.parametrize("gen", [1, 2, 10])
+@pytest.mark.parametrize("hw,cin,cout,res,batch", [((64, 96), 64, 64, True, 3), ((37, 45), 64, 96, False, 2), ((80, 80), 88, 88, False, 2),
+                                                   ((56, 56), 64, 128, True, 5), ((30, 18), 96, 64, True, 3)])
+def test_stride2_family(ctx, monkeypatch, gen, hw, cin, cout, res, batch):
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    monkeypatch.setenv("FID_FORCE_GEN", str(gen))
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    if cin == 64:
+        net.add(Conv("s", "input", 3, cin, act="relu"))
+    else:                                   # the first conv of a net has 16 / 32 / 64 couts: widen with a second one
+        net.add(Conv("s0", "input", 3, 64, act="relu"))
+        net.add(Conv("s", "s0", 64, cin, act="relu"))
+    if res:
+        net.add(Conv("d", "s", cin, cout, k=1, stride=2, pad=0))
+        net.add(Conv("c", "s", cin, cout, stride=2, act="prelu", res="d"))
+    else:
+        net.add(Conv("c", "s", cin, cout, stride=2, act="relu"))
+    net.outputs = ["c"]
+    P = archs.synth_params(net, seed=11)
+    images = np.random.default_rng(4).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    cn.run(images)
+    got = cn.read("c", batch)
+    cn.close()
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["c"]
+    ref = np.transpose(ref, (0, 2, 3, 1))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 6e-3

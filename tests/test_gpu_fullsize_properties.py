@@ -53,7 +53,10 @@ def test_full_size_properties():
     assert np.isfinite(emb).all() and np.abs(emb).max() < 6e4
 
     # ---- the fp32 oracle on 4 of the 64 frames: head tensors of the batch-64 detector run and embeddings of the batch-64
-    # recogniser run (same tolerances as test_gpu_nets.py: scores 3e-3, bbox/kps 3e-2 stride units, cosine 1e-3)
+    # recogniser run (tolerances of test_gpu_nets.py: bbox/kps 3e-2 stride units, cosine 1e-3; sigmoid scores 4e-3 here instead of the 3e-3
+    # of the 320x320 tests: at 640x640 the stride-32 head sums fp16-rounded activations of deeper, larger maps -- tools/head_error.py
+    # measures 2.4e-3 .. 3.3e-3 on that head across four different kernel plans (old kernels only / heuristic plan / autotuned with and
+    # without the generation-9/10 kernels) and 1.1e-3 .. 1.6e-3 on the stride-8 / 16 heads: summation-order noise, not a kernel property)
     from oracle import align as oalign, nets as onets, pipeline as opipe
     run(frames)
     for fi in (0, 21, 42, 63):
@@ -62,7 +65,7 @@ def test_full_size_properties():
         for name in det_net.outputs:
             fused = det.read(name, B)[fi:fi + 1]
             sc_, bb_, kp_ = ref[name]
-            assert np.abs(fused[..., 0:2].reshape(1, -1, 1) - sc_).max() < 3e-3, (fi, name)
+            assert np.abs(fused[..., 0:2].reshape(1, -1, 1) - sc_).max() < 4e-3, (fi, name)
             assert np.abs(fused[..., 2:10].reshape(1, -1, 4) - bb_).max() < 3e-2, (fi, name)
             assert np.abs(fused[..., 10:30].reshape(1, -1, 10) - kp_).max() < 3e-2, (fi, name)
         oe, ocrop = opipe.embed(frames[fi], kps[fi, 0].reshape(5, 2), rec_net, rec_P)     # same landmarks as the device used
