@@ -320,8 +320,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
                         const int oy = oy0 + r;
                         f32x4 v;
                         if (!BORDER) v = acc[t][r] + bmid;
-                        else if (TH == 14 && r > 0 && r < TH - 1) v = acc[t][r] + bmid;   // exact 14-row tiling: only a tile's first / last row can be a border row
-                        else v = acc[t][r] + (oy == 0 ? btop : (oy == a.H - 1 ? bbot : bmid));
+                        else v = acc[t][r] + (oy == 0 ? btop : (oy == a.H - 1 ? bbot : bmid));   // (a scalar compare + 4 selects per row)
                         if (RES) {
                             const half4 h = __builtin_bit_cast(half4, rr[r - r1]);
                             v += __builtin_convertvector(h, f32x4);
@@ -551,7 +550,10 @@ bool conv_wr_resident_ok(const ConvArgs &a) {
 int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident) {
     FID_REQUIRE(c.w_alt, "conv3x3_wr needs the fragment-order weights (repack kind 2)");
     FID_REQUIRE(resident ? conv_wr_resident_ok(c) : ((nt == 2 && cb == 128) || (nt == 1 && cb == 64)), "conv3x3_wr: no %d x %d variant (resident %d)", nt, cb, resident);
-    const bool t14 = c.H % 14 == 0 && c.W % 14 == 0;
+    // tile edge 14 or 16: whichever computes fewer pixels for this map (14 fits IResNet's 112 / 56 / 28 / 14 maps exactly and a 40x40
+    // map in 3x3 tiles of 196 = 91 % useful pixels, where 16x16 tiles compute 48x48 for 69 %)
+    auto padded = [&](int t) { return (long long)cdiv(c.H, t) * t * cdiv(c.W, t) * t; };
+    const bool t14 = padded(14) * 16 <= padded(16) * 14;      // 14-wide tiles leave 2 of 16 lanes idle: require the pixel saving to cover that
     const int TH = t14 ? 14 : 16;
     WRArgs a{};
     a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;

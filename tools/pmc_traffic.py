@@ -15,7 +15,8 @@ import json
 import os
 import sys
 
-CONV = ("conv_mfma_kernel", "conv_mfma_dma_kernel", "conv3x3_direct", "conv3x3_chunked", "conv3x3_pp", "conv3x3_pc", "conv_mfma_pc_kernel", "scrfd_stem_fused", "stem_conv_mfma")
+CONV = ("conv_mfma_kernel", "conv_mfma_dma_kernel", "conv3x3_direct", "conv3x3_chunked", "conv3x3_pp", "conv3x3_pc", "conv_mfma_pc_kernel", "conv3x3_wr", "conv3x3_s2",
+        "scrfd_stem_fused", "stem_conv_mfma")
 
 
 def total(run_dir, counter):
