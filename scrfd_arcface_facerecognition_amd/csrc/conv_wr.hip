@@ -58,8 +58,9 @@ struct WRArgs {
     int tiles_x, tiles_per_img, n_tiles, n_cblk, n_items, n_chunks;
     FastDiv d_cblk, d_tpi, d_tx;
     unsigned in_bytes, out_bytes, w_bytes;
+    int tab_off, ncls;   // LDS offset of the bias [ncls][Cout_p] + slope [Cout_p] fp32 tables; ncls = 9 with CF_BORDER else 1 (0: no bias)
     int stagger;  // experiment: workgroups in the second half of the grid (the co-resident ones) start this many x 64 cycles late
-    int ablate;   // FID_WR_ABLATE timing experiments (wrong results): 1 no step barrier, 2 no patch pieces, 4 no weight reloads, 8 no epilogue, 16 no LDS fragment reads
+    int ablate;   // FID_WR_ABLATE timing experiments (wrong results): 1 no step barrier, 2 no patch pieces, 4 no weight reloads, 8 no epilogue, 32 stores dropped, 64 no residual loads
 };
 
 // TH: tile rows (14 | 16); NT: tiles per item; NW: waves = 16-cout fragments per item;
@@ -173,7 +174,10 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     f32x4 acc[NT][TH];
 
     // one tap column of a step: PH pixel-fragment rows x (up to) 3 taps x NT tiles
-    constexpr int PD = NT == 1 ? (NCH == 3 ? 2 : 4) : 2;                         // pixel fragments read ahead (a fragment feeds <= 3*NT MFMAs = 48*NT cycles; an LDS read takes > 100)
+#ifndef WR_PD_NT2
+#define WR_PD_NT2 2
+#endif
+    constexpr int PD = NT == 1 ? (NCH == 3 ? 2 : 4) : WR_PD_NT2;                         // pixel fragments read ahead (a fragment feeds <= 3*NT MFMAs = 48*NT cycles; an LDS read takes > 100)
     auto compute_col = [&](const char *sP, int dx_, auto wb_tag) {
         constexpr int WB = decltype(wb_tag)::value * 9;
         // the eight per-lane fragment bases of this slot, made opaque: every read is then "base register + immediate" -- left to
@@ -185,14 +189,16 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 pb[par][c] = pbase[par][c] + slot_off;
+#ifndef WR_NO_PB
                 asm volatile("" : "+v"(pb[par][c]));
+#endif
             }
         half8 pq[PD + 1][NT];
         auto load_p = [&](int q, int set) {                     // q = dx * PH + patch row
             const int K = (q % PH) * PW + q / PH;               // lin = K + frow
 #pragma unroll
             for (int t = 0; t < NT; t++)
-                pq[set][t] = *(const half8 *)(smem + ((a.ablate & 16) ? (pb[K & 1][(K >> 1) & 3] & 15) : pb[K & 1][(K >> 1) & 3] + (K * 64 + t * P_BYTES)));
+                pq[set][t] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + (K * 64 + t * P_BYTES)));
         };
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) {
@@ -225,7 +231,11 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     // rows per pass: what the free patch slot holds -- or, resident variant, the whole tile at once in the residual / staging region
     constexpr int HR = NCH > 0 ? TH : ((TH / 2) < (SLOT / (16 * ROWB)) ? (TH / 2) : (SLOT / (16 * ROWB)));
     constexpr int NPASS = (TH + HR - 1) / HR;
-    constexpr int ST_I = (HR * 16 * CPX + NW * 64 - 1) / (NW * 64), EPI_ST = NPASS * NT * ST_I;   // write-out instructions per wave and pass / item
+#ifndef WR_DIRECT
+#define WR_DIRECT 0
+#endif
+    constexpr bool DIRECT = WR_DIRECT && NCH == 0;               // streaming variants: 8-byte stores straight from the accumulator layout, no staging, no barriers
+    constexpr int ST_I = (HR * 16 * CPX + NW * 64 - 1) / (NW * 64), EPI_ST = DIRECT ? NT * TH : NPASS * NT * ST_I;   // write-out instructions per wave and pass / item
     constexpr int RG = NCH > 0 ? 2 : (((TH == 16 && NT == 2) && HR > 4) ? 4 : HR);   // residual rows in registers at a time (resident variant: they come from LDS, just in time)
     constexpr int EPI_RL = NT * NPASS * ((HR + RG - 1) / RG) * RG;                   // residual loads per item (rows past a pass / the tile: out of bounds)
     static_assert(HR >= 1 && (NCH > 0 || HR * 16 * ROWB <= SLOT), "staging area");
@@ -240,6 +250,17 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         const int c0 = wave * 16 + fq * 4, cc = c0 < a.Cout_p ? c0 : 0;
         if (a.bias && !(a.flags & CF_BORDER)) k_bias = *(const f32x4 *)(a.bias + cc);
         if (a.act == ACT_PRELU) k_sl = *(const f32x4 *)(a.slope + cc);
+    }
+    // bias rows / PReLU slopes in LDS for the kernel's lifetime: an item's epilogue reads them with ds_read instead of global loads whose
+    // latency (one to three L2 round trips per item) sat on its critical path
+    const float *sTab = (const float *)(smem + a.tab_off);
+    {
+        float *tb = (float *)(smem + a.tab_off);
+        const int nb = a.ncls * a.Cout_p;
+        for (int i = tid; i < nb; i += NW * 64) tb[i] = a.bias[i];
+        for (int i = tid; i < a.Cout_p; i += NW * 64) tb[nb + i] = a.act == ACT_PRELU ? a.slope[i] : 1.f;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        raw_barrier();
     }
     auto issue_residual = [&](int item_) {                      // exactly RP instructions (resident variant, layers with a residual)
         int pair, cb;
@@ -277,44 +298,67 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         if constexpr (NCH > 0) {
             bmid = k_bias; sl = k_sl;
         } else {
-            if (a.bias && !BORDER) bmid = *(const f32x4 *)(a.bias + cc);
-            if (ACT == ACT_PRELU) sl = *(const f32x4 *)(a.slope + cc);
+            if (a.ncls && !BORDER) bmid = *(const f32x4 *)(sTab + cc);
+            if (ACT == ACT_PRELU) sl = *(const f32x4 *)(sTab + a.ncls * a.Cout_p + cc);
         }
         const unsigned rstride = (unsigned)(a.W * a.Cout_p * 2);
         // my 8 bytes of a staged pixel row (256 B = 16 chunks of 8 couts): chunk wave*2 + q4/2, XOR-swizzled by the pixel column
         const int st_w = fr * ROWB + (((wave * 2 + (q4 >> 1) + fr) % CPX) << 4) + (q4 & 1) * 8;    // chunk rotated by the pixel column: no bank pile-up
         if (NCH > 0 && RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of the residual tile (issued a step ago) are in LDS
-        if (NCH == 0 || RES) raw_barrier();                     // every wave is done reading the slot / everybody's residual pieces landed
+        if (!DIRECT && (NCH == 0 || RES)) raw_barrier();        // every wave is done reading the slot / everybody's residual pieces landed
+        // residual groups (streaming variant: 8-byte loads in the accumulator layout), software-pipelined: group g + 1 is requested before
+        // group g is consumed, so only the item's first group waits for memory
+        constexpr int GPP = (HR + RG - 1) / RG, NGRP = NT * NPASS * GPP;
+        unsigned t_base[NT];
+        bool t_ok[NT];
+        int t_oy0[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int tile = pair * NT + t;
+            int n, ty, tx;
+            decode_tile(tile < a.n_tiles ? tile : 0, n, ty, tx);
+            t_oy0[t] = ty * TH;
+            t_ok[t] = tile < a.n_tiles && co_ok && fr < TW && tx * TW + fr < a.W;
+            t_base[t] = (unsigned)((((n * a.H + ty * TH) * a.W + tx * TW + fr) * a.Cout_p + co0) * 2);
+        }
+        u32x2 rrA[RG], rrB[RG];
+        auto load_group = [&](int gi, u32x2 (&rr)[RG]) {        // gi -> (tile, pass, group in pass); exactly RG loads
+            const int t = gi / (NPASS * GPP), rem = gi - t * (NPASS * GPP), r0 = (rem / GPP) * HR, r1 = r0 + (rem % GPP) * RG;
+#pragma unroll
+            for (int r = 0; r < RG; r++)
+                rr[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, (t_ok[t] && r1 + r < r0 + HR && r1 + r < TH && t_oy0[t] + r1 + r < a.H && !(a.ablate & 64)) ? t_base[t] + (r1 + r) * rstride : OOB, 0, 0);
+        };
+        if (RES && NCH == 0) load_group(0, rrA);
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const int tile = pair * NT + t;
             int n, ty, tx;
             decode_tile(tile < a.n_tiles ? tile : 0, n, ty, tx);
             const int oy0 = ty * TH, ox0 = tx * TW, ox = ox0 + fr;
-            const bool lane_ok = tile < a.n_tiles && co_ok && fr < TW && ox < a.W;
-            const unsigned base = (unsigned)((((n * a.H + oy0) * a.W + ox) * a.Cout_p + co0) * 2);
             f32x4 btop = bmid, bbot = bmid;
             if (BORDER) {       // exact fold of a BatchNorm in front of the zero-padded conv: the bias row depends on the pixel's border class
                 const int xc = ox == 0 ? 0 : (ox == a.W - 1 ? 2 : 1);
-                btop = *(const f32x4 *)(a.bias + (size_t)(0 + xc) * a.Cout_p + cc);
-                bmid = *(const f32x4 *)(a.bias + (size_t)(3 + xc) * a.Cout_p + cc);
-                bbot = *(const f32x4 *)(a.bias + (size_t)(6 + xc) * a.Cout_p + cc);
+                btop = *(const f32x4 *)(sTab + (0 + xc) * a.Cout_p + cc);
+                bmid = *(const f32x4 *)(sTab + (3 + xc) * a.Cout_p + cc);
+                bbot = *(const f32x4 *)(sTab + (6 + xc) * a.Cout_p + cc);
             }
 #pragma unroll
             for (int r0 = 0; r0 < TH; r0 += HR) {
 #pragma unroll
                 for (int r1 = r0; r1 < r0 + HR && r1 < TH; r1 += RG) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int gi = (t * NPASS + r0 / HR) * GPP + (r1 - r0) / RG;     // (compile-time: the nest is fully unrolled)
                     u32x2 rr[RG];
                     if (RES && NCH > 0) {                        // resident variant: the residual tile is in LDS, staged layout
 #pragma unroll
                         for (int r = 0; r < RG; r++)
                             if (r1 + r < r0 + HR && r1 + r < TH) rr[r] = *(const u32x2 *)(sR + (r1 + r) * (16 * ROWB) + st_w);
-                    } else if (RES) {                            // (rows beyond the tile: out-of-bounds offset -- the operation count stays exact)
+                    } else if (RES) {
+                        if (gi + 1 < NGRP) { if (gi & 1) load_group(gi + 1, rrA); else load_group(gi + 1, rrB); }
 #pragma unroll
-                        for (int r = 0; r < RG; r++)
-                            rr[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, (lane_ok && r1 + r < r0 + HR && r1 + r < TH && oy0 + r1 + r < a.H && !(a.ablate & 64)) ? base + (r1 + r) * rstride : OOB, 0, 0);
+                        for (int r = 0; r < RG; r++) rr[r] = (gi & 1) ? rrB[r] : rrA[r];
                     }
-                    if (r1 == r0 && t + r0 > 0) raw_barrier();  // the pass before has been read back
+                    if (!DIRECT && r1 == r0 && t + r0 > 0) raw_barrier();  // the pass before has been read back
 #pragma unroll
                     for (int r = r1; r < r1 + RG && r < r0 + HR && r < TH; r++) {
                         const int oy = oy0 + r;
@@ -328,9 +372,11 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
                         if (ACT == ACT_PRELU) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + sl * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
                         half4 h = __builtin_convertvector(v, half4);
                         if (ACT == ACT_RELU) h = __builtin_elementwise_max(h, half4{0, 0, 0, 0});
-                        *(half4 *)(stage + (r - r0) * (16 * ROWB) + st_w) = h;
+                        if (DIRECT) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs_out, (t_ok[t] && oy < a.H && !(a.ablate & 32)) ? t_base[t] + r * rstride : OOB, 0, 0);
+                        else *(half4 *)(stage + (r - r0) * (16 * ROWB) + st_w) = h;
                     }
                 }
+                if (DIRECT) continue;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 raw_barrier();                                  // the half tile is staged
                 // write-out: 16-byte slot g = (i*NW + wave)*64 + lane of the pass = pixel g / CPX, chunk g % CPX.  NW*64 / CPX = 32 for every
@@ -520,19 +566,23 @@ template <int TH, int NT, int NW, int NCH>
 static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
     constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     constexpr int RS_BYTES = NCH > 0 ? ((TH * 16 * NW * 32 + 1023) / 1024) * 1024 : 0;      // resident variant: the residual tile
-    constexpr int LDS = 2 * NT * P_BYTES + 1024 + RS_BYTES;
+    a.ncls = a.bias ? ((a.flags & CF_BORDER) ? 9 : 1) : 0;
+    a.tab_off = 2 * NT * P_BYTES + 1024 + RS_BYTES;
+    const int LDS = a.tab_off + (a.ncls + 1) * a.Cout_p * 4;
+    FID_REQUIRE(LDS <= 160 * 1024, "conv3x3_wr: %d bytes of LDS", LDS);
     a.n_cblk = cdiv(a.Cout_p, NW * 16);
     a.n_items = cdiv(n_tiles, NT) * a.n_cblk;
     a.d_cblk = fastdiv_make(a.n_cblk);
     FID_REQUIRE(NCH == 0 || (a.n_chunks == NCH && a.n_cblk == 1), "conv3x3_wr: resident variant %d x %d on %d chunks / %d cout blocks", NW * 16, NCH, a.n_chunks, a.n_cblk);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_lds = 0;
+    if (LDS > attr_lds) {
         FID_HIP(hipFuncSetAttribute((const void *)conv3x3_wr<TH, NT, NW, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
+        attr_lds = LDS;
     }
     // waves per CU by registers: > 168 VGPRs -> two per SIMD (8 per CU); the one-tile streaming variant stays below 168 -> three per SIMD
-    const int wg_per_cu = std::max(1, std::min((NT == 1 && NCH == 0 ? 12 : 8) / NW, (160 * 1024) / LDS));
-    const int grid = std::min(a.n_items, ctx->num_cus * wg_per_cu);
+    const int wg_per_cu = std::max(1, std::min((NT == 1 && NCH == 0 && TH == 14 ? 12 : 8) / NW, (160 * 1024) / LDS));
+    static const int wgpc_env = getenv("FID_WR_WGPC") ? atoi(getenv("FID_WR_WGPC")) : 0;
+    const int grid = std::min(a.n_items, ctx->num_cus * (wgpc_env > 0 ? wgpc_env : wg_per_cu));
     hipLaunchKernelGGL((conv3x3_wr<TH, NT, NW, NCH>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
