@@ -78,7 +78,7 @@ int conv_pcr_launch(fid_ctx *ctx, const ConvArgs &a);
 // conv_wr.hip (generation 9): weights in registers, waves split by cout, a pair of tiles x 128 couts per item; needs w_alt (kind 2)
 bool conv_wr_applicable(const ConvArgs &a);
 bool conv_wr_resident_ok(const ConvArgs &a);
-int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident);
+int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident, int ring);
 
 // conv_s2.hip (generation 10): 3x3 / stride 2 with parity-plane patches and resident weights (64 / 96 input channels); needs w_alt (kind 2)
 bool conv_s2_applicable(const ConvArgs &a);

@@ -830,6 +830,7 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
         d.gen = 9; d.ksplit = 1; d.bk = 32;
         d.bm = 512; d.bn = 128; out.push_back(d);      // a pair of tiles x 128 couts
         d.bm = 256; d.bn = 64; out.push_back(d);       // one tile x 64 couts (few tiles: more items)
+        d.ns = 4; out.push_back(d); d.ns = 0;          // ... with the patches three steps ahead (small batches: one workgroup per CU)
         if (conv_wr_resident_ok(a)) { d.bm = 256; d.bn = a.Cout_p; d.ns = 1; out.push_back(d); }   // the layer's weights resident in registers
     }
     if (conv_pc_applicable(a)) {
@@ -909,7 +910,7 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 7) return conv_pcr_launch(ctx, a);
     if (plan.gen == 8) return conv_pc2_launch(ctx, a);
     if (plan.gen == 10) return conv_s2_launch(ctx, a);
-    if (plan.gen == 9) return conv_wr_launch(ctx, a, plan.bm / 256, plan.bn, plan.ns);
+    if (plan.gen == 9) return conv_wr_launch(ctx, a, plan.bm / 256, plan.bn, plan.ns == 1, plan.ns == 4 ? 4 : 2);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);
     FID_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 4 == 0, "conv: channel padding (Cin_p=%d Cout_p=%d)", a.Cin_p, a.Cout_p);

@@ -67,7 +67,9 @@ struct WRArgs {
 // NCH = 0: the weights stream (one register set, re-loaded column by column one step ahead);
 // NCH = 2 | 3: layers with NCH*32 input channels and at most NW*16 couts -- ALL weights of the layer (NCH x 9 fragments per wave) stay
 //              in registers for the kernel's lifetime: only patches are fetched (SCRFD's 64 / 96-channel stacks at 160x160 / 80x80)
-template <int TH, int NT, int NW, int NCH>
+// NS: patch slots -- pieces are requested NS - 1 steps ahead (4: the one-tile variant on small batches, where a step is ~1 us, shorter
+//     than a trip to memory, and there is no second workgroup on the CU to hide it)
+template <int TH, int NT, int NW, int NCH, int NS = 2>
 __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     constexpr int CBW = NW * 16;                                // couts per item
     constexpr int TW = TH;                                      // tile stride in x (16 lanes per fragment; lanes >= TW are not stored)
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         char *dst = smem + slot * SLOT;
 #pragma unroll
         for (int k = 0; k < MAX_P; k++) {
-            const int j = wave + NW * k < NT * P_BLKS ? wave + NW * k : 2 * NT * P_BLKS - slot * NT * P_BLKS;   // surplus piece: zeros into the spare KB behind the slots
+            const int j = wave + NW * k < NT * P_BLKS ? wave + NW * k : (NS - slot) * NT * P_BLKS;   // surplus piece: zeros into the spare KB behind the slots
             int pk = p_pk[k];
             asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
             const int h = pk >> 24, py = pk & 255;
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     // reads it from LDS: a tile's epilogue then has no global round trip on its critical path (measured before: 64-100 us of a 146-192 us
     // layer were the per-tile bias / residual load latencies, with only two workgroups per CU to hide them)
     constexpr int RS_BLKS = (TH * 16 * ROWB + 1023) / 1024, RP = (RS_BLKS + NW - 1) / NW;
-    char *sR = smem + 2 * SLOT + 1024;
+    char *sR = smem + NS * SLOT + 1024;
     f32x4 k_bias = f32x4{0.f, 0.f, 0.f, 0.f}, k_sl = f32x4{1.f, 1.f, 1.f, 1.f};
     if constexpr (NCH > 0) {
         const int c0 = wave * 16 + fq * 4, cc = c0 < a.Cout_p ? c0 : 0;
@@ -279,7 +281,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             const int oy = ty * TH + pr, ox = tx * TW + pc;
             const bool ok = j < RS_BLKS && pl < TH * 16 && pair < a.n_tiles && pc < TW && oy < a.H && ox < a.W && c * 8 < a.Cout_p;
             const unsigned vo = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout_p + c * 8) * 2) : OOB;
-            char *dst = j < RS_BLKS ? sR + j * 1024 : smem + 2 * SLOT;      // surplus piece: the spare KB
+            char *dst = j < RS_BLKS ? sR + j * 1024 : smem + NS * SLOT;     // surplus piece: the spare KB
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (__attribute__((address_space(3))) void *)dst, 16, vo, 0, 0, 0);
         }
     };
@@ -423,7 +425,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     }
     if constexpr (NCH > 0) {
         // ================= resident weights: a.n_chunks == NCH, one cout block =================
-        static_assert(NT == 1, "resident variant: one tile per item");
+        static_assert(NT == 1 && NS == 2, "resident variant: one tile per item, two patch slots");
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             load_col(0, c, 0, w[c * 9 + 0], w[c * 9 + 3], w[c * 9 + 6]);
@@ -473,16 +475,24 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
     // ---- operation order per wave and step s (vmcnt retires in order, so every wait below names only OLDER operations):
-    //   top:  MAX_P patch pieces of step s+1
+    //   top:  MAX_P patch pieces of step s+D (D = NS - 1 slots ahead)
     //   after column 0 / 1: 3 weight loads = that column of step s+1
     //   after column 2: [the item's last chunk: E = EPI_ST stores (+ NT*TH residual loads) of the epilogue], then column 2 of step s+1
-    // wait at the top for the pieces of step s:            younger = 9 weight loads (+ E of the step before)
+    // wait at the top for the pieces of step s:            younger = D x 9 weight loads + (D - 1) x MAX_P pieces (+ E of an epilogue in between)
     // wait before column dx for its 3 fragments (step s):  younger = 6 weight loads + MAX_P pieces (+ E for columns 0 and 1)
+    constexpr int D = NS - 1;                                   // steps a patch is requested ahead
     Cursor cf;                                                  // what the next patch issue fetches
     cf.item = bid; cf.ck = 0;
     cursor_decode(cf);
-    issue_patches(cf, 0);
     int w_cb = cf.cb, w_ck = 0, w_item = bid;                   // what the next weight column loads belong to
+    Cursor none = cf;                                           // "no tile": keeps the operation count exact past the last step
+#pragma unroll
+    for (int h = 0; h < NT; h++) none.n[h] = -1;
+#pragma unroll
+    for (int d = 0; d < D; d++) {                               // pieces of steps 0 .. D-1
+        if (d < n_steps) { issue_patches(cf, d); cursor_next(cf); }
+        else issue_patches(none, d);
+    }
     load_col(w_cb, w_ck, 0, w[0], w[3], w[6]);
     load_col(w_cb, w_ck, 1, w[1], w[4], w[7]);
     load_col(w_cb, w_ck, 2, w[2], w[5], w[8]);
@@ -494,43 +504,39 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         }
     };
     w_next();
-    cursor_next(cf);
     int ck = 0, item = bid;
     constexpr int CAP = 63;                                      // vmcnt is a 6-bit counter
-    constexpr int N_TOP = 9, N_COL = 6 + MAX_P;
+    // younger than the pieces of step s (requested at the top of step s - D): D x 9 weight loads, the pieces of the D - 1 steps between
+    constexpr int N_TOP = D * 9 + (D - 1) * MAX_P, N_COL = 6 + MAX_P;
     constexpr int E1 = EPI_ST, E2 = EPI_ST + EPI_RL;
-    int e_prev = 0;                                             // 0 / 1 / 2: the step before ended an item (without / with residual loads)
-#define WR_WAIT(N0, REGS)                                                                                            \
+    int e_type = 0, e_age = 99;                                 // the last epilogue: 1 / 2 (without / with residual loads), and how many steps ago
+#define WR_WAIT_E(N0, ET, REGS)                                                                                      \
     do {                                                                                                             \
-        if (e_prev == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N0) > CAP ? CAP : (N0)) : "memory");              \
-        else if (e_prev == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N0) + E1 > CAP ? CAP : (N0) + E1) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N0) + E2 > CAP ? CAP : (N0) + E2) : "memory");                  \
+        if ((ET) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N0) > CAP ? CAP : (N0)) : "memory");                \
+        else if ((ET) == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N0) + E1 > CAP ? CAP : (N0) + E1) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N0) + E2 > CAP ? CAP : (N0) + E2) : "memory");                \
         REGS;                                                                                                        \
     } while (0)
+    int slot = 0, slot_in = D % NS;                             // slot of step s / slot the pieces of step s + D go to
     for (int s = 0; s < n_steps; s++) {
-        WR_WAIT(N_TOP, (void)0);                                // my pieces of step s have landed
+        const int e_top = e_age <= D ? e_type : 0, e_col = e_age == 1 ? e_type : 0;   // (two epilogues inside the window: only one is counted -- a longer wait, never a shorter one)
+        WR_WAIT_E(N_TOP, e_top, (void)0);                       // my pieces of step s have landed
         if (!(a.ablate & 1)) raw_barrier();                     // ... everybody's; and everyone is done with step s-1's slot
-        const bool more = s + 1 < n_steps;
-        if (a.ablate & 2) { if (more) cursor_next(cf); }
-        else if (more) { issue_patches(cf, (s + 1) & 1); cursor_next(cf); }
-        else {                                                  // keep the operation count of the step: MAX_P surplus pieces
-            Cursor none = cf;
-#pragma unroll
-            for (int h = 0; h < NT; h++) none.n[h] = -1;
-            issue_patches(none, (s + 1) & 1);
-        }
+        if (a.ablate & 2) { if (s + D < n_steps) cursor_next(cf); }
+        else if (s + D < n_steps) { issue_patches(cf, slot_in); cursor_next(cf); }
+        else issue_patches(none, slot_in);
         if (ck == 0) {
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int r = 0; r < TH; r++) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const char *sP = smem + (s & 1) * SLOT;
-        WR_WAIT(N_COL, asm volatile("" : "+v"(w[0]), "+v"(w[3]), "+v"(w[6])));
+        const char *sP = smem + slot * SLOT;
+        WR_WAIT_E(N_COL, e_col, asm volatile("" : "+v"(w[0]), "+v"(w[3]), "+v"(w[6])));
         __builtin_amdgcn_sched_barrier(0);
         compute_col(sP, 0, std::integral_constant<int, 0>{});
         if (!(a.ablate & 4)) load_col(w_cb, w_ck, 0, w[0], w[3], w[6]);   // (past the last step these fetch a valid, unused block: the count stays exact)
-        WR_WAIT(N_COL, asm volatile("" : "+v"(w[1]), "+v"(w[4]), "+v"(w[7])));
+        WR_WAIT_E(N_COL, e_col, asm volatile("" : "+v"(w[1]), "+v"(w[4]), "+v"(w[7])));
         __builtin_amdgcn_sched_barrier(0);
         compute_col(sP, 1, std::integral_constant<int, 0>{});
         if (!(a.ablate & 4)) load_col(w_cb, w_ck, 1, w[1], w[4], w[7]);
@@ -538,18 +544,20 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         asm volatile("" : "+v"(w[2]), "+v"(w[5]), "+v"(w[8]));
         __builtin_amdgcn_sched_barrier(0);
         compute_col(sP, 2, std::integral_constant<int, 0>{});
-        e_prev = 0;
+        e_age++;
         if (++ck == a.n_chunks) {                               // the epilogue's own loads (bias rows, residual) make the compiler wait for
-            if (!(a.ablate & 8)) epilogue(item, smem + (s & 1) * SLOT);   // everything older: the pieces and columns 0 / 1, issued >= 1/3 step ago --
-            e_prev = a.res ? 2 : 1;                             // which is why column 2 is re-loaded only after it
+            if (!(a.ablate & 8)) epilogue(item, smem + slot * SLOT);      // everything older: the pieces and columns 0 / 1, issued >= 1/3 step ago --
+            e_type = a.res ? 2 : 1; e_age = 1;                  // which is why column 2 is re-loaded only after it
             ck = 0; item += gridDim.x;
         }
         if (!(a.ablate & 4)) load_col(w_cb, w_ck, 2, w[2], w[5], w[8]);
         if (s + 2 < n_steps) w_next();
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        slot_in = slot_in + 1 == NS ? 0 : slot_in + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the surplus loads target registers / LDS of this wave: drain before exit
     }
-#undef WR_WAIT
+#undef WR_WAIT_E
 }
 
 }  // namespace
@@ -562,12 +570,12 @@ bool conv_wr_applicable(const ConvArgs &a) {
            (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo && a.res_Cp == a.Cout_p));
 }
 
-template <int TH, int NT, int NW, int NCH>
+template <int TH, int NT, int NW, int NCH, int NS = 2>
 static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
     constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     constexpr int RS_BYTES = NCH > 0 ? ((TH * 16 * NW * 32 + 1023) / 1024) * 1024 : 0;      // resident variant: the residual tile
     a.ncls = a.bias ? ((a.flags & CF_BORDER) ? 9 : 1) : 0;
-    a.tab_off = 2 * NT * P_BYTES + 1024 + RS_BYTES;
+    a.tab_off = NS * NT * P_BYTES + 1024 + RS_BYTES;
     const int LDS = a.tab_off + (a.ncls + 1) * a.Cout_p * 4;
     FID_REQUIRE(LDS <= 160 * 1024, "conv3x3_wr: %d bytes of LDS", LDS);
     a.n_cblk = cdiv(a.Cout_p, NW * 16);
@@ -576,14 +584,14 @@ static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
     FID_REQUIRE(NCH == 0 || (a.n_chunks == NCH && a.n_cblk == 1), "conv3x3_wr: resident variant %d x %d on %d chunks / %d cout blocks", NW * 16, NCH, a.n_chunks, a.n_cblk);
     static int attr_lds = 0;
     if (LDS > attr_lds) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_wr<TH, NT, NW, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_wr<TH, NT, NW, NCH, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_lds = LDS;
     }
     // waves per CU by registers: > 168 VGPRs -> two per SIMD (8 per CU); the one-tile streaming variant stays below 168 -> three per SIMD
     const int wg_per_cu = std::max(1, std::min((NT == 1 && NCH == 0 && TH == 14 ? 12 : 8) / NW, (160 * 1024) / LDS));
     static const int wgpc_env = getenv("FID_WR_WGPC") ? atoi(getenv("FID_WR_WGPC")) : 0;
     const int grid = std::min(a.n_items, ctx->num_cus * (wgpc_env > 0 ? wgpc_env : wg_per_cu));
-    hipLaunchKernelGGL((conv3x3_wr<TH, NT, NW, NCH>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
+    hipLaunchKernelGGL((conv3x3_wr<TH, NT, NW, NCH, NS>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
 }
@@ -597,7 +605,7 @@ bool conv_wr_resident_ok(const ConvArgs &a) {
 
 // nt x cb: 2 x 128 (large batches: a pair of tiles x 128 couts on 8 waves) | 1 x 64 (four waves, two workgroups per CU: enough items
 // for every CU when there are only a few hundred tiles); resident: one tile x all couts with the layer's weights kept in registers
-int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident) {
+int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident, int ring) {
     FID_REQUIRE(c.w_alt, "conv3x3_wr needs the fragment-order weights (repack kind 2)");
     FID_REQUIRE(resident ? conv_wr_resident_ok(c) : ((nt == 2 && cb == 128) || (nt == 1 && cb == 64)), "conv3x3_wr: no %d x %d variant (resident %d)", nt, cb, resident);
     // tile edge 14 or 16: whichever computes fewer pixels for this map (14 fits IResNet's 112 / 56 / 28 / 14 maps exactly and a 40x40
@@ -639,6 +647,7 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
         return FID_E_INVALID;
     }
     if (nt == 2) return t14 ? wr_launch_t<14, 2, 8, 0>(ctx, a, a.n_tiles) : wr_launch_t<16, 2, 8, 0>(ctx, a, a.n_tiles);
+    if (ring == 4) return t14 ? wr_launch_t<14, 1, 4, 0, 4>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, 4, 0, 4>(ctx, a, a.n_tiles);
     return t14 ? wr_launch_t<14, 1, 4, 0>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, 4, 0>(ctx, a, a.n_tiles);
 }
 

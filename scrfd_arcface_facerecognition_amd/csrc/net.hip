@@ -416,7 +416,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 if (const char *fn = getenv("FID_FORCE_NS")) {       // tests: one ring variant of generation 2 / 5
                     std::vector<ConvPlan> only;
                     for (const ConvPlan &c : cands)
-                        if (((c.gen == 2 || c.gen == 5) && c.ns == atoi(fn)) || (c.gen == 9 && (c.ns ? 3 : c.bm / 256) == atoi(fn))) only.push_back(c);
+                        if (((c.gen == 2 || c.gen == 5) && c.ns == atoi(fn)) || (c.gen == 9 && (c.ns == 1 ? 3 : (c.ns == 4 ? 4 : c.bm / 256)) == atoi(fn))) only.push_back(c);
                     if (!only.empty()) cands = only;
                 }
                 const float pc2_bias = getenv("FID_PC2_BIAS") ? (float)atof(getenv("FID_PC2_BIAS")) : 1.f;
@@ -429,7 +429,8 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 for (const ConvPlan &c : cands) {
                     if (c.partial_bytes > net->partial_cap) continue;
                     float tmin = 1e30f;
-                    for (int rep = 0; rep < 5; rep++) {
+                    static const int tune_reps = getenv("FID_TUNE_REPS") ? std::max(2, atoi(getenv("FID_TUNE_REPS"))) : 5;
+                    for (int rep = 0; rep < tune_reps; rep++) {
                         FID_TRY(set_alt_weights(ctx, net, oi, a, c));
                         FID_HIP(hipEventRecord(e0, ctx->stream));
                         FID_TRY(conv_launch(ctx, a, c));
