@@ -9,7 +9,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfaceid.so")
+# FID_LIB names another build of the same library in this directory (libfaceid_asan.so from `make asan`); never a CPU fallback
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("FID_LIB") or "libfaceid.so"))
 
 c_void_pp = C.POINTER(C.c_void_p)
 c_int_p = C.POINTER(C.c_int)

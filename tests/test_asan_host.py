@@ -1,0 +1,53 @@
+"""Host-side sanitizer run: loads the AddressSanitizer + UBSan build of the C-ABI library (`make -C
+scrfd_arcface_facerecognition_amd/csrc asan`) into a child python and drives every entry point that needs no GPU -- symbol table,
+error paths of context / net / gallery / communicator creation on a box without a device, plan-file parsing, the RCCL unique id.
+Skipped when libfaceid_asan.so has not been built (it is not part of build(): 45 s of extra compile); no GPU work, no oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(os.path.dirname(HERE), "scrfd_arcface_facerecognition_amd")
+ASAN_LIB = os.path.join(PKG, "libfaceid_asan.so")
+
+CHILD = r"""
+import ctypes as C, os, sys, tempfile
+import numpy as np
+from scrfd_arcface_facerecognition_amd import _lib
+lib = _lib.load()
+assert _lib.LIB_PATH.endswith("libfaceid_asan.so")
+assert lib.fid_abi_version() == 1
+n = C.c_int(-1)
+rc = lib.fid_device_count(C.byref(n))
+have_gpu = rc == 0 and n.value > 0
+ctx = C.c_void_p()
+rc = lib.fid_ctx_create(99, None, C.byref(ctx))              # no such device: error path, message set, nothing leaked
+assert rc != 0 and lib.fid_last_error()
+assert lib.fid_ctx_create(0, None, None) != 0               # null out-pointer
+ident = (C.c_ubyte * 128)()
+rc = lib.fid_comm_unique_id(ident, 128)                       # dlopen(librccl) + ncclGetUniqueId on the host
+assert rc == 0 or lib.fid_last_error()
+assert lib.fid_comm_unique_id(ident, 8) != 0                  # short buffer refused
+assert lib.fid_net_plan_load(None, b"/nonexistent", None) != 0
+assert lib.fid_net_plan_save(None, b"/nonexistent") != 0
+assert lib.fid_gallery_info(None, None, None, None) != 0
+assert lib.fid_comm_info(None, None, None) != 0
+assert lib.fid_net_set_sub_batch(None, 4) != 0
+print("asan-host-ok", "gpu" if have_gpu else "nogpu")
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(ASAN_LIB), reason="libfaceid_asan.so not built (make -C .../csrc asan)")
+def test_host_entry_points_under_asan_ubsan():
+    rt = subprocess.run(["make", "-s", "-C", os.path.join(PKG, "csrc"), "asan-rt"], capture_output=True, text=True,
+                        check=True).stdout.strip()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, FID_LIB="libfaceid_asan.so",
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=87", UBSAN_OPTIONS="halt_on_error=1:exitcode=88",
+               PYTHONPATH=os.path.dirname(HERE))
+    p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    assert "asan-host-ok" in p.stdout
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr
