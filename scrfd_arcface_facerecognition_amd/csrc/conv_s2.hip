@@ -122,6 +122,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
         }
     };
 
+    // first patch and all weights in one trip to memory (both cold at launch: ~1-2 us each)
+    Cursor cf;
+    cf.tile = bid; cf.ck = 0;
+    cursor_decode(cf);
+    issue_patches(cf, 0);
+    cursor_next(cf);
     // ---- weights: all NCH x 9 fragments of this wave's 16 couts, resident (repack kind 2: [cb128][chunk][cf 0..7][dx][dy][lane])
     const unsigned long long wp = (unsigned long long)a.w;
     const i32x4 rs_w = i32x4{(int)(unsigned)wp, (int)((unsigned)(wp >> 32) & 0xFFFFu), (int)a.w_bytes, 0x00020000};
@@ -260,11 +266,6 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
 
     // ---- steps: (tile, chunk); patches one step ahead.  Operation order per wave: [top: MAX_P pieces of step s+1] [last chunk:
     // EPI_RL residual loads (if any) + EPI_ST stores].  Top wait for the pieces of step s: younger = the epilogue of the step before.
-    Cursor cf;
-    cf.tile = bid; cf.ck = 0;
-    cursor_decode(cf);
-    issue_patches(cf, 0);
-    cursor_next(cf);
     constexpr int E1 = EPI_ST, E2 = EPI_ST + EPI_RL;
     int e_prev = 0, tile = bid, s = 0;
     auto step = [&](auto c_tag) {

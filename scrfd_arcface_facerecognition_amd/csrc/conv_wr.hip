@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
 #define WR_PD_NT2 2
 #endif
     constexpr int PD = NT == 1 ? (NCH == 3 ? 2 : 4) : WR_PD_NT2;                         // pixel fragments read ahead (a fragment feeds <= 3*NT MFMAs = 48*NT cycles; an LDS read takes > 100)
-    auto compute_col = [&](const char *sP, int dx_, auto wb_tag) {
+    auto compute_col = [&](const char *sP, int dx_, auto wb_tag, auto &&row_hook) {
         constexpr int WB = decltype(wb_tag)::value * 9;
         // the eight per-lane fragment bases of this slot, made opaque: every read is then "base register + immediate" -- left to
         // itself the compiler hoists one address register PER READ out of the step loop (54 VGPRs of loop-invariant addresses)
@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             for (int r = 0; r < PH; r++) {
                 const int q = dx * PH + r;
                 if (r + PD < PH) load_p(q + PD, (r + PD) % (PD + 1));
+                row_hook(dx, r);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dy = 0; dy < 3; dy++) {
@@ -236,6 +237,13 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
 #ifndef WR_DIRECT
 #define WR_DIRECT 0
 #endif
+#ifndef WR_DEFER
+#define WR_DEFER 1
+#endif
+    // resident variants: an item's finished tile is only STAGED (fp16, pixel rows) at the end of its last step; the 16-byte row stores
+    // are issued one by one between the matrix rows of the next step, so the write burst of all CUs no longer sits between two steps
+    // with every matrix pipe idle (measured on SCRFD layer1: 127 us with the epilogue, 99 with its stores dropped, 85 without it)
+    constexpr bool DEFER = WR_DEFER && NCH == 2;
     constexpr bool DIRECT = WR_DIRECT && NCH == 0;               // streaming variants: 8-byte stores straight from the accumulator layout, no staging, no barriers
     constexpr int ST_I = (HR * 16 * CPX + NW * 64 - 1) / (NW * 64), EPI_ST = DIRECT ? NT * TH : NPASS * NT * ST_I;   // write-out instructions per wave and pass / item
     constexpr int RG = NCH > 0 ? 2 : (((TH == 16 && NT == 2) && HR > 4) ? 4 : HR);   // residual rows in registers at a time (resident variant: they come from LDS, just in time)
@@ -255,15 +263,17 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     }
     // bias rows / PReLU slopes in LDS for the kernel's lifetime: an item's epilogue reads them with ds_read instead of global loads whose
     // latency (one to three L2 round trips per item) sat on its critical path
+    // Called AFTER the first patch pieces and weight fragments have been requested: the three cold fetches of a launch (tables, weights,
+    // first patch: ~1-2 us each from HBM / the Infinity Cache) then share one wait instead of running back to back.
     const float *sTab = (const float *)(smem + a.tab_off);
-    {
+    auto fill_tables = [&]() {
         float *tb = (float *)(smem + a.tab_off);
         const int nb = a.ncls * a.Cout_p;
         for (int i = tid; i < nb; i += NW * 64) tb[i] = a.bias[i];
         for (int i = tid; i < a.Cout_p; i += NW * 64) tb[nb + i] = a.act == ACT_PRELU ? a.slope[i] : 1.f;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         raw_barrier();
-    }
+    };
     auto issue_residual = [&](int item_) {                      // exactly RP instructions (resident variant, layers with a residual)
         int pair, cb;
         decode_item(item_, pair, cb);
@@ -286,6 +296,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         }
     };
     auto epilogue_body = [&](int item, char *stage, auto act_tag, auto res_tag, auto border_tag) {
+        constexpr bool STAGE_ONLY = DEFER;                       // resident variants: the write-out happens inside the NEXT step's matrix columns
         constexpr int ACT = decltype(act_tag)::value;
         constexpr bool RES = decltype(res_tag)::value, BORDER = decltype(border_tag)::value;
         int pair, cb;
@@ -380,6 +391,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
                 }
                 if (DIRECT) continue;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (STAGE_ONLY) continue;                       // (the next step's barrier publishes the staged tile)
                 raw_barrier();                                  // the half tile is staged
                 // write-out: 16-byte slot g = (i*NW + wave)*64 + lane of the pass = pixel g / CPX, chunk g % CPX.  NW*64 / CPX = 32 for every
                 // NW, so pixel = 32 i + q0 and chunk = c with q0, c per-lane constants: both addresses are affine in i
@@ -426,27 +438,75 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     if constexpr (NCH > 0) {
         // ================= resident weights: a.n_chunks == NCH, one cout block =================
         static_assert(NT == 1 && NS == 2, "resident variant: one tile per item, two patch slots");
+        Cursor cf;
+        cf.item = bid; cf.ck = 0;
+        cursor_decode(cf);
+        issue_patches(cf, 0);                                   // first patch, all weights, tables: one trip to memory
+        cursor_next(cf);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             load_col(0, c, 0, w[c * 9 + 0], w[c * 9 + 3], w[c * 9 + 6]);
             load_col(0, c, 1, w[c * 9 + 1], w[c * 9 + 4], w[c * 9 + 7]);
             load_col(0, c, 2, w[c * 9 + 2], w[c * 9 + 5], w[c * 9 + 8]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fill_tables();                                          // (ends with vmcnt(0) + barrier)
 #pragma unroll
         for (int i = 0; i < NCH * 9; i++) asm volatile("" : "+v"(w[i]));
-        Cursor cf;
-        cf.item = bid; cf.ck = 0;
-        cursor_decode(cf);
-        issue_patches(cf, 0);
-        cursor_next(cf);
         constexpr int E1 = EPI_ST;
         int e_prev = 0, item = bid, s = 0;
         const bool has_res = a.res != nullptr;
+        auto no_hook = [](int, int) {};
+        // deferred write-out of the tile staged in sR (item `pend`): per-lane constants as in epilogue_body's write-out loop
+        int pend = -1;
+        const char *wo_src = sR;
+        unsigned wo_g0 = OOB;
+        int wo_rows = 0, wo_pr0 = 0;
+        const unsigned wo_rstride = (unsigned)(a.W * a.Cout_p * 2);
+        auto wo_setup = [&]() {
+            int lo2 = lane;
+            asm volatile("" : "+v"(lo2));
+            int n, ty, tx;
+            decode_tile(pend >= 0 && pend < a.n_tiles ? pend : 0, n, ty, tx);
+            const int wl = wave * 64 + lo2, q0 = wl / CPX, c = wl - q0 * CPX;
+            const int pr0 = q0 >> 4, pc = q0 & 15;
+            const int oy0 = ty * TH, oxx = tx * TW + pc, co = c * 8;
+            const bool okc = pend >= 0 && pend < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p && !(a.ablate & 32);
+            wo_src = sR + q0 * ROWB + (((c + pc) % CPX) << 4);
+            wo_g0 = (unsigned)((((n * a.H + oy0 + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
+            wo_rows = okc ? (a.H - oy0 < TH ? a.H - oy0 : TH) - pr0 : 0;      // 2 i < wo_rows: the lane may store row 2 i + pr0 of the tile
+            wo_pr0 = pr0;
+        };
+        u32x4 wo_v = u32x4{0u, 0u, 0u, 0u};
+        auto wo_one_read = [&](int i) {
+            const bool in_pass = 2 * i + wo_pr0 < HR;
+            wo_v = *(const u32x4 *)(wo_src + (in_pass ? i * 32 * ROWB : 0));
+        };
+        auto wo_one_store = [&](int i) {
+            const bool ok = 2 * i + wo_pr0 < HR && 2 * i < wo_rows;
+            __builtin_amdgcn_raw_buffer_store_b128(wo_v, rs_out, ok ? wo_g0 + (unsigned)(2 * i) * wo_rstride : OOB, 0, 0);
+        };
+        // write-out i = 3 dx + j of a step: LDS read in front of matrix row 1 + 5 j of column dx, store in front of row 4 + 5 j
+        // (exactly ST_I stores per wave in every first step of an item, whether or not a tile is pending: the counts stay exact)
+        auto wo_hook = [&](int dx, int r) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int i = 3 * dx + j;
+                if (i >= ST_I) continue;
+                if (r == 1 + 5 * j) wo_one_read(i);
+                if (r == 4 + 5 * j) wo_one_store(i);
+            }
+        };
+        static_assert(!DEFER || (ST_I <= 9 && PH >= 15), "deferred write-out schedule");
         auto step = [&](auto c_tag) {
             constexpr int C = decltype(c_tag)::value;
-            if (e_prev == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // my pieces of step s have landed
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E1 > 63 ? 63 : E1) : "memory");            // (an item's stores may fly on)
+            if constexpr (DEFER) {
+                // younger than my pieces of step s (requested at the top of step s - 1): the ST_I stores of a first step -- nothing else
+                if (C == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_I) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (e_prev == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // my pieces of step s have landed
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(E1 > 63 ? 63 : E1) : "memory");            // (an item's stores may fly on)
+            }
             raw_barrier();
             if (s + 1 < n_steps) { issue_patches(cf, (s + 1) & 1); cursor_next(cf); }
             if (C == NCH - 1 && has_res) issue_residual(item);  // lands during this step; read in the epilogue behind a vmcnt(0)
@@ -455,14 +515,22 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
                 for (int r = 0; r < TH; r++) acc[0][r] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             const char *sP = smem + (s & 1) * SLOT;
-            compute_col(sP, 0, c_tag);
-            compute_col(sP, 1, c_tag);
-            compute_col(sP, 2, c_tag);
+            if constexpr (DEFER && C == 0) {
+                wo_setup();
+                compute_col(sP, 0, c_tag, wo_hook);
+                compute_col(sP, 1, c_tag, wo_hook);
+                compute_col(sP, 2, c_tag, wo_hook);
+            } else {
+                compute_col(sP, 0, c_tag, no_hook);
+                compute_col(sP, 1, c_tag, no_hook);
+                compute_col(sP, 2, c_tag, no_hook);
+            }
             e_prev = 0;
             if (C == NCH - 1) {
                 if (!(a.ablate & 8)) epilogue(item, sR);    // outputs are staged in place of the residual tile
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 e_prev = 1;
+                pend = (a.ablate & 8) ? -1 : item;
                 item += gridDim.x;
             }
             s++;
@@ -471,6 +539,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             step(std::integral_constant<int, 0>{});
             step(std::integral_constant<int, 1>{});
             if constexpr (NCH > 2) step(std::integral_constant<int, 2>{});
+        }
+        if constexpr (DEFER) {                                  // the last item's tile
+            raw_barrier();
+            wo_setup();
+#pragma unroll
+            for (int i = 0; i < ST_I; i++) { wo_one_read(i); wo_one_store(i); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -504,6 +578,8 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         }
     };
     w_next();
+    fill_tables();                                              // drains the pieces and the first weight set too: the counted waits of step 0 then find less in flight than they allow
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]));
     int ck = 0, item = bid;
     constexpr int CAP = 63;                                      // vmcnt is a 6-bit counter
     // younger than the pieces of step s (requested at the top of step s - D): D x 9 weight loads, the pieces of the D - 1 steps between
@@ -534,16 +610,16 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         const char *sP = smem + slot * SLOT;
         WR_WAIT_E(N_COL, e_col, asm volatile("" : "+v"(w[0]), "+v"(w[3]), "+v"(w[6])));
         __builtin_amdgcn_sched_barrier(0);
-        compute_col(sP, 0, std::integral_constant<int, 0>{});
+        compute_col(sP, 0, std::integral_constant<int, 0>{}, [](int, int) {});
         if (!(a.ablate & 4)) load_col(w_cb, w_ck, 0, w[0], w[3], w[6]);   // (past the last step these fetch a valid, unused block: the count stays exact)
         WR_WAIT_E(N_COL, e_col, asm volatile("" : "+v"(w[1]), "+v"(w[4]), "+v"(w[7])));
         __builtin_amdgcn_sched_barrier(0);
-        compute_col(sP, 1, std::integral_constant<int, 0>{});
+        compute_col(sP, 1, std::integral_constant<int, 0>{}, [](int, int) {});
         if (!(a.ablate & 4)) load_col(w_cb, w_ck, 1, w[1], w[4], w[7]);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_COL) : "memory");   // column 2 was loaded AFTER the epilogue of the step before: no E term
         asm volatile("" : "+v"(w[2]), "+v"(w[5]), "+v"(w[8]));
         __builtin_amdgcn_sched_barrier(0);
-        compute_col(sP, 2, std::integral_constant<int, 0>{});
+        compute_col(sP, 2, std::integral_constant<int, 0>{}, [](int, int) {});
         e_age++;
         if (++ck == a.n_chunks) {                               // the epilogue's own loads (bias rows, residual) make the compiler wait for
             if (!(a.ablate & 8)) epilogue(item, smem + slot * SLOT);      // everything older: the pieces and columns 0 / 1, issued >= 1/3 step ago --

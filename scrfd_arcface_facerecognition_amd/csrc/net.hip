@@ -442,6 +442,9 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                     }
                     float score = c.ksplit > 1 ? tmin * 1.1f : tmin;
                     if (c.gen == 8) score *= pc2_bias;          // experiments: FID_PC2_BIAS < 1 prefers the two-tile kernel although it is slower alone
+                    static const int tune_verbose = getenv("FID_TUNE_LOG") ? atoi(getenv("FID_TUNE_LOG")) : 0;
+                    if (tune_verbose >= 2)
+                        fprintf(stderr, "[cand] op %d gen %d tile %dx%dx%d ns %d split %d: %.1f us\n", oi, c.gen, c.bm, c.bn, c.bk, c.ns, c.ksplit, tmin * 1e3f);
                     if (score < best) { best = score; plan = c; }
                 }
                 (void)hipEventDestroy(e0);
