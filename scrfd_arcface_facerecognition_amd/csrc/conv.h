@@ -37,7 +37,7 @@ struct ConvArgs {
 // must hold ksplit*M*Cout_p floats when the plan splits K (query with conv_plan first).
 struct ConvPlan {
     int bm, bn, bk, ksplit;
-    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr, 8 = conv_pc2, 9 = conv_wr, 10 = conv_s2
+    int gen;   // 0 = conv_direct, 1 = register-staged double buffer, 2 = LDS-DMA ring, 3 = conv_chunked, 4 = conv_pp, 5 = conv_pc (bn = couts per work item), 6 = LDS-DMA ring with producer waves, 7 = conv_pcr, 8 = conv_pc2, 9 = conv_wr, 10 = conv_s2, 11 = conv_gw
     int ns;    // ring slots (gen 2); 5 = 4 slots + fragment prefetch across K-steps
     size_t partial_bytes;
 };
@@ -49,8 +49,8 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan);
 // alternate weight packing a plan's kernel wants in ConvArgs::w_alt (0 = none); repack.hip builds it
 int plan_alt_kind(const ConvPlan &plan);
-size_t repack_bytes(int kind, int Cout_p, int Cin_p);
-int repack_weights(fid_ctx *ctx, int kind, const void *src, void *dst, int Cout_p, int Cin_p);
+size_t repack_bytes(int kind, int Cout_p, int Cin_p, int taps = 9);
+int repack_weights(fid_ctx *ctx, int kind, const void *src, void *dst, int Cout_p, int Cin_p, int taps = 9);
 
 // conv_direct.hip: 3x3/s1 conv with LDS-resident weights + haloed patches (<= 64 channels in and out)
 bool conv_direct_applicable(const ConvArgs &a);
@@ -83,6 +83,11 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident
 // conv_s2.hip (generation 10): 3x3 / stride 2 with parity-plane patches and resident weights (64 / 96 input channels); needs w_alt (kind 2)
 bool conv_s2_applicable(const ConvArgs &a);
 int conv_s2_launch(fid_ctx *ctx, const ConvArgs &a);
+
+// conv_gw.hip (generation 11): implicit GEMM (any 1x1 / 2x2 / 3x3, any stride) with the weights in registers, only the pixel operand
+// through LDS; bm = 64 | 128 output pixels x bn = 128 | 256 couts per item; needs w_alt (kind 3)
+bool conv_gw_applicable(const ConvArgs &a);
+int conv_gw_launch(fid_ctx *ctx, const ConvArgs &a, int bm, int bn);
 
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,

@@ -825,6 +825,15 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
     if (conv_pcr_applicable(a)) { ConvPlan d{}; d.gen = 7; d.ksplit = 1; d.bm = 256; d.bn = 64; d.bk = 32; out.push_back(d); }
     if (conv_pc2_applicable(a)) { ConvPlan d{}; d.gen = 8; d.ksplit = 1; d.bm = 512; d.bn = 64; d.bk = 32; out.push_back(d); }
     if (conv_s2_applicable(a)) { ConvPlan d{}; d.gen = 10; d.ksplit = 1; d.bm = 128; d.bn = a.Cout_p; d.bk = 32; out.push_back(d); }
+    if (conv_gw_applicable(a)) {
+        ConvPlan d{};
+        d.gen = 11; d.ksplit = 1; d.bk = 32;
+        for (int bm : {128, 64})
+            for (int bn : {256, 128}) {
+                if (bn == 256 && a.Cout_p <= 128) continue;
+                d.bm = bm; d.bn = bn; out.push_back(d);
+            }
+    }
     if (conv_wr_applicable(a)) {
         ConvPlan d{};
         d.gen = 9; d.ksplit = 1; d.bk = 32;
@@ -899,6 +908,7 @@ int plan_alt_kind(const ConvPlan &plan) {
     static const bool pc2_packed = getenv("FID_PC2_PLAIN") == nullptr;
     if (plan.gen == 8) return pc2_packed ? 1 : 0;
     if (plan.gen == 9 || plan.gen == 10) return 2;
+    if (plan.gen == 11) return 3;
     return 0;
 }
 
@@ -910,6 +920,7 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 7) return conv_pcr_launch(ctx, a);
     if (plan.gen == 8) return conv_pc2_launch(ctx, a);
     if (plan.gen == 10) return conv_s2_launch(ctx, a);
+    if (plan.gen == 11) return conv_gw_launch(ctx, a, plan.bm, plan.bn);
     if (plan.gen == 9) return conv_wr_launch(ctx, a, plan.bm / 256, plan.bn, plan.ns == 1, plan.ns == 4 ? 4 : 2);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);

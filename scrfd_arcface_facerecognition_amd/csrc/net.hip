@@ -327,8 +327,8 @@ int set_alt_weights(fid_ctx *ctx, fid_net *net, int oi, ConvArgs &a, const ConvP
     auto it = net->alt_w.find(key);
     if (it == net->alt_w.end()) {
         void *p = nullptr;
-        FID_HIP(hipMalloc(&p, repack_bytes(kind, a.Cout_p, a.Cin_p) + 256));
-        FID_TRY(repack_weights(ctx, kind, a.w, p, a.Cout_p, a.Cin_p));
+        FID_HIP(hipMalloc(&p, repack_bytes(kind, a.Cout_p, a.Cin_p, a.kh * a.kw) + 256));
+        FID_TRY(repack_weights(ctx, kind, a.w, p, a.Cout_p, a.Cin_p, a.kh * a.kw));
         it = net->alt_w.emplace(key, p).first;
     }
     a.w_alt = it->second;

@@ -256,7 +256,9 @@ def test_build_targets_matches_reference_semantics(ctx, tmp_path, caplog):
         assert 1 - float(ref @ e / np.linalg.norm(ref) / np.linalg.norm(e)) < 1e-3
         # the per-image reference call sequence gives the same vector as the batched path (batch-1 vs batch-n kernels: fp16 noise)
         _, kpss = detector.detect(images[b], max_num=1)
-        assert np.array_equal(kpss[0], okps[0])
+        # (another batch size -> other autotuned kernels -> another fp32 summation order in the heads: landmarks agree to fp16 noise of
+        # the head tensors, 3e-2 stride units in test_gpu_nets.py = well below a quarter pixel at these strides, not bit for bit)
+        assert np.abs(kpss[0] - okps[0]).max() < 0.25
         e1 = recognizer(images[b], kpss[0])
         assert 1 - float(e1 @ e / np.linalg.norm(e1) / np.linalg.norm(e)) < 1e-3
         ti += 1
