@@ -106,6 +106,8 @@ def op_bytes(cn, oi, n):
     b += tb(int(op[W_SRC])) * n if int(op[W_SRC]) >= 0 else cn.in_hw[0] * cn.in_hw[1] * 3 * n
     if int(op[W_RES]) >= 0:
         b += tb(int(op[W_RES])) * n
+    if int(op[0]) == 2 and int(op[20]) > 0:               # conv fused with the block's shortcut: a second output tensor (csrc/net.h W_X_DST2)
+        b += tb(int(op[20]) - 1) * n
     return b
 
 

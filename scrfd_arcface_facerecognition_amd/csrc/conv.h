@@ -20,6 +20,7 @@ struct ConvArgs {
     const float *slope; // fp32 [Cout_p] PReLU slopes (ACT_PRELU)
     const void *res;    // fp16 residual [B, res_H, res_W, res_Cp] or NULL
     void *out;          // fp16/fp32 [B, Ho, Wo, Cout_p]
+    void *out2;         // fused shortcut + stride-2 conv (lower.py): second fp16 output [B, Ho, Wo, Cout_p] fed by weight / bias rows Cout_p .. w_rows-1 (no activation), or NULL
     float *partial;     // split-K slabs fp32 [ksplit][M][Cout_p]
     unsigned long long *amax;  // CF_ARGMAX: packed (sortable(value) << 32 | ~(amax_col0 + column)) per row
     int amax_col0;             // CF_ARGMAX: global index of column 0 (gallery shards)

@@ -759,6 +759,7 @@ static bool dma_have(int bm, int bn, int bk) {
 }
 
 ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
+    if (a.out2) { ConvPlan d{}; d.gen = 10; d.ksplit = 1; d.bm = 128; d.bn = a.w_rows; d.bk = 32; return d; }
     ConvPlan p{};
     static const bool use_v1 = getenv("FID_CONV_V1") != nullptr;
     auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
@@ -814,6 +815,11 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
 }
 
 std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split) {
+    if (a.out2) {                                   // fused shortcut + stride-2 conv: one kernel takes it
+        std::vector<ConvPlan> only;
+        if (conv_s2_applicable(a)) { ConvPlan d{}; d.gen = 10; d.ksplit = 1; d.bm = 128; d.bn = a.w_rows; d.bk = 32; only.push_back(d); }
+        return only;
+    }
     std::vector<ConvPlan> out;
     if (conv_direct_applicable(a)) { ConvPlan d{}; d.gen = 0; d.ksplit = 1; out.push_back(d); }
     if (conv_chunked_applicable(a) && !getenv("FID_NO_CHUNKED")) {

@@ -52,6 +52,7 @@ struct S2Args {
     const float *slope;
     const void *res;
     void *out;
+    void *out2;           // DUAL: the second output (the block's shortcut), same shape as out
     int H, W, Ho, Wo, Cin_p, Cout_p;
     int act, flags;
     int tiles_x, tiles_per_img, n_tiles;
@@ -60,11 +61,18 @@ struct S2Args {
 };
 
 // NW: waves = 16-cout fragments (Cout_p <= NW*16); NCH: 32-channel chunks (Cin_p = NCH*32)
-template <int NW, int NCH>
-__global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
-    constexpr int CBW = NW * 16, ROWB = CBW * 2, CPX = NW * 2;
+// DUAL: TWO convs over the same patch in one launch -- waves 0 .. NW/2-1 are the 3x3 / stride-2 conv (output `out`, activation a.act),
+// waves NW/2 .. NW-1 the block's shortcut, a 2x2 / stride-2 conv stored as a 3x3 one whose taps (0, *) and (*, 0) are zero (output
+// `out2`, no activation): they skip those taps' fragment reads and MFMAs.  The weight / bias tables hold both convs' rows back to back;
+// the tile is written out in two passes (each half staged through the finished patch slot), all NW waves storing in both.
+template <int NW, int NCH, bool DUAL = false>
+__global__ void __launch_bounds__(NW * 64, DUAL ? 3 : 2) conv3x3_s2(const S2Args a) {
+    constexpr int NH = DUAL ? NW / 2 : NW;                                      // waves (= cout fragments) of one output
+    constexpr int CBW = NH * 16, ROWB = CBW * 2, CPX = NH * 2;
     constexpr int MAX_P = (P_BLKS + NW - 1) / NW;
-    constexpr int ST_I = (TOH * TOW * CPX + NW * 64 - 1) / (NW * 64);          // write-out instructions per wave and tile
+    constexpr int PPI = NW * 64 / CPX, RPI = PPI / 16;                          // pixels / tile rows one write-out instruction of the workgroup covers
+    static_assert(PPI % 16 == 0, "a write-out instruction covers whole tile rows");
+    constexpr int ST_I = (TOH * TOW * CPX + NW * 64 - 1) / (NW * 64);          // write-out instructions per wave and pass
     static_assert(TOH * TOW * ROWB <= P_BYTES, "staging area");
     extern __shared__ __attribute__((aligned(16))) char smem[];                 // 2 patch slots + 1 spare KB
 
@@ -83,6 +91,8 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
     const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, a.out_bytes, 0x00020000);
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res ? a.res : a.out), 0, a.out_bytes, 0x00020000);
+    const auto rs_out2 = __builtin_amdgcn_make_buffer_rsrc((void *)(DUAL ? a.out2 : a.out), 0, a.out_bytes, 0x00020000);
+    const int part = DUAL ? (wave >= NH ? 1 : 0) : 0, wave_l = wave - part * NH;   // which output this wave computes; its fragment inside it
 
     // ---- my patch pieces: piece j = wave + NW k covers LDS pixels 16 j .. 16 j + 15 (4 lanes per pixel); LDS pixel lin = pr*33 + q,
     // q < 17: even plane, input column 2 q; q >= 17: odd plane, input column 2 (q - 17) + 1 (columns relative to the patch's first)
@@ -131,7 +141,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
     // ---- weights: all NCH x 9 fragments of this wave's 16 couts, resident (repack kind 2: [cb128][chunk][cf 0..7][dx][dy][lane])
     const unsigned long long wp = (unsigned long long)a.w;
     const i32x4 rs_w = i32x4{(int)(unsigned)wp, (int)((unsigned)(wp >> 32) & 0xFFFFu), (int)a.w_bytes, 0x00020000};
-    const int w_voff = wave * 9216 + lane * 16;
+    const int w_voff = ((wave >> 3) * NCH * 8 + (wave & 7)) * 9216 + lane * 16;    // (more than 8 fragments: the next 128-cout block)
     half8 w[NCH * 9];                                           // w[chunk*9 + dy*3 + dx]
 #pragma unroll
     for (int c = 0; c < NCH; c++)
@@ -152,9 +162,9 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
     // bias / slopes of this lane's 4 couts: one cout block, so they never change
     f32x4 k_bias = f32x4{0.f, 0.f, 0.f, 0.f}, k_sl = f32x4{1.f, 1.f, 1.f, 1.f};
     {
-        const int c0 = wave * 16 + fq * 4, cc = c0 < a.Cout_p ? c0 : 0;
+        const int c0 = wave * 16 + fq * 4, cc = (DUAL || c0 < a.Cout_p) ? c0 : 0;     // (DUAL: the table has both outputs' rows)
         if (a.bias) k_bias = *(const f32x4 *)(a.bias + cc);
-        if (a.act == ACT_PRELU) k_sl = *(const f32x4 *)(a.slope + cc);
+        if (!DUAL && a.act == ACT_PRELU) k_sl = *(const f32x4 *)(a.slope + cc);
     }
 
     // ---- pixel fragment addresses: lin = K + frow with K a compile-time constant (conv_wr.hip): base register + immediate
@@ -165,21 +175,38 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
         for (int c = 0; c < 4; c++) pbase[par][c] = frow * 64 + ((fq ^ ((((frow + par) >> 1) + c) & 3)) << 4);
 
     f32x4 acc[TOH];
-    constexpr int PD = 3;                                       // fragments read ahead
+    constexpr int PD = DUAL ? 2 : 3;                            // fragments read ahead (DUAL: twelve waves at <= 168 VGPRs)
     constexpr int NF = PR * 3;                                  // fragments per step: (patch row, dx), dx fastest
-    auto compute = [&](const char *sP, auto c_tag) {
+    auto compute = [&](const char *sP, auto c_tag, auto short_tag) {
         constexpr int WB = decltype(c_tag)::value * 9;
+        constexpr bool SHORT = decltype(short_tag)::value;       // the shortcut's waves: taps dy, dx in {1, 2} only
+        auto used = [](int f) {                                  // does fragment (patch row, dx) feed any MFMA of this wave
+            const int pr = f / 3, dx = f % 3;
+            if (!SHORT) return true;
+            if (dx == 0) return false;
+            for (int dy = 1; dy < 3; dy++)
+                if (pr - dy >= 0 && !((pr - dy) & 1) && (pr - dy) / 2 < TOH) return true;
+            return false;
+        };
         int pb[2][4];
         const int slot_off = (int)(sP - smem);
 #pragma unroll
         for (int par = 0; par < 2; par++)
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                pb[par][c] = pbase[par][c] + slot_off;
+                if (DUAL) {                                     // (recomputed per step: eight fewer registers across the loop)
+                    int lo_ = lane;
+                    asm volatile("" : "+v"(lo_));
+                    const int fr_ = lo_ & 15, fq_ = lo_ >> 4;
+                    pb[par][c] = fr_ * 64 + ((fq_ ^ ((((fr_ + par) >> 1) + c) & 3)) << 4) + slot_off;
+                } else {
+                    pb[par][c] = pbase[par][c] + slot_off;
+                }
                 asm volatile("" : "+v"(pb[par][c]));
             }
         half8 pq[PD + 1];
         auto load_p = [&](int f, int set) {                     // f = pr*3 + dx: E[ox] / O[ox] / E[ox + 1]
+            if (!used(f)) return;
             const int pr = f / 3, dx = f % 3;
             const int K = pr * RW + (dx == 0 ? 0 : (dx == 1 ? NE : 1));
             pq[set] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + K * 64));
@@ -194,6 +221,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
 #pragma unroll
             for (int dy = 0; dy < 3; dy++) {
                 if ((pr - dy) < 0 || ((pr - dy) & 1)) continue;
+                if (SHORT && (dy == 0 || dx == 0)) continue;
                 const int o = (pr - dy) / 2;
                 if (o >= TOH) continue;
                 acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[WB + dy * 3 + dx], pq[f % (PD + 1)], acc[o], 0, 0, 0);
@@ -203,20 +231,20 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
     };
 
     // ---- epilogue of `tile` (sums in acc): bias (+ residual) + activation in the accumulator layout, staged, written out as 16-byte slots
-    constexpr int EPI_ST = ST_I, EPI_RL = TOH;
+    constexpr int EPI_ST = (DUAL ? 2 : 1) * ST_I, EPI_RL = TOH;
     auto epilogue_body = [&](int tile, char *stage, auto act_tag, auto res_tag) {
         constexpr int ACT = decltype(act_tag)::value;
-        constexpr bool RES = decltype(res_tag)::value;
+        constexpr bool RES = decltype(res_tag)::value && !DUAL;
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const int fr = lo & 15, q4 = lo >> 4;
-        const int co0 = wave * 16 + q4 * 4;
+        const int co0 = wave_l * 16 + q4 * 4;
         const bool co_ok = co0 < a.Cout_p;
         int n, ty, tx;
         decode_tile(tile < a.n_tiles ? tile : 0, n, ty, tx);
         const int oy0 = ty * TOH, ox0 = tx * TOW, ox = ox0 + fr;
         const unsigned rstride = (unsigned)(a.Wo * a.Cout_p * 2);
-        const int st_w = fr * ROWB + (((wave * 2 + (q4 >> 1) + fr) % CPX) << 4) + (q4 & 1) * 8;
+        const int st_w = fr * ROWB + (((wave_l * 2 + (q4 >> 1) + fr) % CPX) << 4) + (q4 & 1) * 8;
         u32x2 rr[TOH];
         if (RES) {
             const bool lane_ok = tile < a.n_tiles && co_ok && ox < a.Wo;
@@ -224,30 +252,41 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
 #pragma unroll
             for (int r = 0; r < TOH; r++) rr[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, (lane_ok && oy0 + r < a.Ho) ? base + r * rstride : OOB, 0, 0);
         }
-        raw_barrier();                                          // every wave is done reading the slot
 #pragma unroll
-        for (int r = 0; r < TOH; r++) {
-            f32x4 v = acc[r] + k_bias;
-            if (RES) v += __builtin_convertvector(__builtin_bit_cast(half4, rr[r]), f32x4);
-            if (ACT == ACT_PRELU) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + k_sl * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
-            half4 h = __builtin_convertvector(v, half4);
-            if (ACT == ACT_RELU) h = __builtin_elementwise_max(h, half4{0, 0, 0, 0});
-            *(half4 *)(stage + r * (16 * ROWB) + st_w) = h;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        raw_barrier();                                          // the tile is staged
-        const int wl = wave * 64 + lo, q0 = wl / CPX, c = wl - q0 * CPX;            // slot (i*NW + wave)*64 + lane = pixel 32 i + q0, chunk c
-        const int pr0 = q0 >> 4, pc = q0 & 15;
-        const int oxx = ox0 + pc, co = c * 8;
-        const bool okc = tile < a.n_tiles && oxx < a.Wo && co < a.Cout_p;
-        const char *lsrc = stage + q0 * ROWB + (((c + pc) % CPX) << 4);
-        const unsigned g0 = (unsigned)((((n * a.Ho + oy0 + pr0) * a.Wo + oxx) * a.Cout_p + co) * 2);
-        const int rows_left = (a.Ho - oy0 < TOH ? a.Ho - oy0 : TOH) - pr0;
+        for (int pass = 0; pass < (DUAL ? 2 : 1); pass++) {
+            raw_barrier();                                      // every wave is done reading the slot / the pass before has been read back
+            if (part == pass) {
 #pragma unroll
-        for (int i = 0; i < ST_I; i++) {
-            const bool in_tile = 2 * i + pr0 < TOH;
-            const u32x4 v = *(const u32x4 *)(lsrc + (in_tile ? i * 32 * ROWB : 0));
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (okc && in_tile && 2 * i < rows_left) ? g0 + (unsigned)(2 * i) * rstride : OOB, 0, 0);
+                for (int r = 0; r < TOH; r++) {
+                    f32x4 v = acc[r] + k_bias;
+                    if (RES) v += __builtin_convertvector(__builtin_bit_cast(half4, rr[r]), f32x4);
+                    if (ACT == ACT_PRELU && pass == 0) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + k_sl * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                    half4 h = __builtin_convertvector(v, half4);
+                    if (ACT == ACT_RELU && pass == 0) h = __builtin_elementwise_max(h, half4{0, 0, 0, 0});
+                    *(half4 *)(stage + r * (16 * ROWB) + st_w) = h;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            raw_barrier();                                      // the (half) tile is staged
+            // write-out: slot (i*NW + wave)*64 + lane = pixel PPI i + q0, chunk c (constants recomputed per pass from an opaque lane id:
+            // they must not stay in registers across the step loop)
+            int lo2 = lo;
+            asm volatile("" : "+v"(lo2));
+            const int wl = wave * 64 + lo2, q0 = wl / CPX, c = wl - q0 * CPX;
+            const int pr0 = q0 >> 4, pc = q0 & 15;
+            const int oxx = ox0 + pc, co = c * 8;
+            const bool okc = tile < a.n_tiles && oxx < a.Wo && co < a.Cout_p;
+            const char *lsrc = stage + q0 * ROWB + (((c + pc) % CPX) << 4);
+            const unsigned g0 = (unsigned)((((n * a.Ho + oy0 + pr0) * a.Wo + oxx) * a.Cout_p + co) * 2);
+            const int rows_left = (a.Ho - oy0 < TOH ? a.Ho - oy0 : TOH) - pr0;
+#pragma unroll
+            for (int i = 0; i < ST_I; i++) {
+                const bool in_tile = RPI * i + pr0 < TOH;
+                const u32x4 v = *(const u32x4 *)(lsrc + (in_tile ? i * PPI * ROWB : 0));
+                const unsigned off = (okc && in_tile && RPI * i < rows_left) ? g0 + (unsigned)(RPI * i) * rstride : OOB;
+                if (pass == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(v, rs_out2, off, 0, 0);
+            }
         }
     };
     auto epilogue = [&](int tile, char *stage) {
@@ -279,7 +318,8 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
 #pragma unroll
             for (int r = 0; r < TOH; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        compute(smem + (s & 1) * P_BYTES, c_tag);
+        if (DUAL && part) compute(smem + (s & 1) * P_BYTES, c_tag, std::integral_constant<bool, true>{});
+        else compute(smem + (s & 1) * P_BYTES, c_tag, std::integral_constant<bool, false>{});
         e_prev = 0;
         if (C == NCH - 1) {
             epilogue(tile, smem + (s & 1) * P_BYTES);
@@ -298,7 +338,15 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_s2(const S2Args a) {
 
 }  // namespace
 
+// the fused form: 64 input channels, 96 + 96 couts, no residual / activation on the second output
+static bool conv_s2_dual_ok(const ConvArgs &a) {
+    return a.out2 != nullptr && a.kh == 3 && a.kw == 3 && a.stride == 2 && a.pad == 1 && a.Cin_p == 64 && a.Cout_p == 96 && a.w_rows == 192 &&
+           a.Ho == (a.H - 1) / 2 + 1 && a.Wo == (a.W - 1) / 2 + 1 && a.Ho >= 8 && a.Wo >= 8 && a.flags == 0 && a.nsig == 0 && a.res == nullptr &&
+           a.act != ACT_PRELU;
+}
+
 bool conv_s2_applicable(const ConvArgs &a) {
+    if (a.out2) return conv_s2_dual_ok(a);
     if (getenv("FID_NO_S2")) return false;
     const int nch = a.Cin_p / CK;
     return a.kh == 3 && a.kw == 3 && a.stride == 2 && a.pad == 1 && a.Cin_p % 32 == 0 && (nch == 2 || nch == 3) &&
@@ -308,18 +356,18 @@ bool conv_s2_applicable(const ConvArgs &a) {
            (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo && a.res_Cp == a.Cout_p));
 }
 
-template <int NW, int NCH>
+template <int NW, int NCH, bool DUAL = false>
 static int s2_launch_t(fid_ctx *ctx, const S2Args &a) {
     constexpr int LDS = 2 * P_BYTES + 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_s2<NW, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_s2<NW, NCH, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     // workgroups per CU: two patch-slot pairs fit LDS; registers allow 12 waves per CU (<= 168 VGPRs) for two chunks, 8 for three
     const int wg_per_cu = std::max(1, std::min((NCH == 2 ? 12 : 8) / NW, 2));
     const int grid = std::min(a.n_tiles, ctx->num_cus * wg_per_cu);
-    hipLaunchKernelGGL((conv3x3_s2<NW, NCH>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
+    hipLaunchKernelGGL((conv3x3_s2<NW, NCH, DUAL>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
 }
@@ -328,7 +376,7 @@ int conv_s2_launch(fid_ctx *ctx, const ConvArgs &c) {
     FID_REQUIRE(c.w_alt, "conv3x3_s2 needs the fragment-order weights (repack kind 2)");
     FID_REQUIRE(conv_s2_applicable(c), "conv3x3_s2: layer not supported");
     S2Args a{};
-    a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
+    a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out; a.out2 = c.out2;
     a.H = c.H; a.W = c.W; a.Ho = c.Ho; a.Wo = c.Wo; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
     a.act = c.act; a.flags = c.flags;
     const int B = c.M / (c.Ho * c.Wo);
@@ -340,7 +388,8 @@ int conv_s2_launch(fid_ctx *ctx, const ConvArgs &c) {
     const size_t ob = (size_t)c.M * c.Cout_p * 2;
     FID_REQUIRE(a.in_bytes <= OOB && ob <= OOB, "conv: tensor larger than 2 GiB");
     a.out_bytes = (unsigned)ob;
-    a.w_bytes = (unsigned)repack_bytes(2, c.Cout_p, c.Cin_p);
+    a.w_bytes = (unsigned)repack_bytes(2, c.w_rows, c.Cin_p);
+    if (c.out2) return s2_launch_t<12, 2, true>(ctx, a);
     const int key = (c.Cout_p / 16) * 10 + c.Cin_p / CK;
     switch (key) {
         case 42: return s2_launch_t<4, 2>(ctx, a);

@@ -30,6 +30,9 @@ enum : int {
     // OP_STEMFUSED (stem_fused.hip): blob offsets of the three convs' packed weights / biases
     W_F_W0 = 20, W_F_B0 = 21, W_F_W1 = 22, W_F_B1 = 23, W_F_W2 = 24, W_F_B2 = 25,
     W_F_MACS_LO = 26, W_F_MACS_HI = 27,   // algorithmic MACs per image of the fused group (cost accounting)
+    // OP_CONV fused with the block's shortcut (lower.py; conv_s2.hip DUAL): second output's tensor id + 1 (0: plain conv), its activation,
+    // padded couts of the first output; W_F_MACS_LO then holds the shortcut's MACs per image
+    W_X_DST2 = 20, W_X_ACT2 = 21, W_X_COUT1P = 22,
 };
 
 // int32 word indices of one tensor record (FID_TENSOR_WORDS = 8 words)

@@ -327,8 +327,8 @@ int set_alt_weights(fid_ctx *ctx, fid_net *net, int oi, ConvArgs &a, const ConvP
     auto it = net->alt_w.find(key);
     if (it == net->alt_w.end()) {
         void *p = nullptr;
-        FID_HIP(hipMalloc(&p, repack_bytes(kind, a.Cout_p, a.Cin_p, a.kh * a.kw) + 256));
-        FID_TRY(repack_weights(ctx, kind, a.w, p, a.Cout_p, a.Cin_p, a.kh * a.kw));
+        FID_HIP(hipMalloc(&p, repack_bytes(kind, a.w_rows, a.Cin_p, a.kh * a.kw) + 256));      // (w_rows = Cout_p except for the fused shortcut + conv op)
+        FID_TRY(repack_weights(ctx, kind, a.w, p, a.w_rows, a.Cin_p, a.kh * a.kw));
         it = net->alt_w.emplace(key, p).first;
     }
     a.w_alt = it->second;
@@ -383,6 +383,12 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             a.bias = bias;
             a.slope = slope;
             a.out = dst.ptr;
+            if (op[W_X_DST2] > 0) {                              // fused shortcut + stride-2 conv: second output, same shape
+                const TensorView d2 = view(net, op[W_X_DST2] - 1, first);
+                FID_REQUIRE(d2.H == dst.H && d2.W == dst.W && d2.Cp == dst.Cp && d2.dtype == dst.dtype && op[W_X_ACT2] == ACT_NONE &&
+                            op[W_X_COUT1P] == dst.Cp, "op %d: bad fused shortcut record", oi);
+                a.out2 = d2.ptr;
+            }
             a.H = src.H; a.W = src.W; a.Cin_p = src.Cp;
             a.Ho = dst.H; a.Wo = dst.W; a.Cout_p = dst.Cp;
             a.w_rows = op[W_WROWS];
@@ -502,7 +508,7 @@ size_t partial_need(fid_ctx *ctx, fid_net *net, int batch) {
     size_t need = 0;
     for (int oi = 0; oi < net->n_ops; oi++) {
         const int32_t *op = &net->ops[(size_t)oi * FID_OP_WORDS];
-        if (op[W_TYPE] != OP_CONV) continue;
+        if (op[W_TYPE] != OP_CONV || op[W_X_DST2] > 0) continue;   // (the fused shortcut + conv op never splits K)
         const TensorView src = view(net, op[W_SRC]), dst = view(net, op[W_DST]);
         ConvArgs a{};
         a.Cin_p = src.Cp; a.Cout_p = dst.Cp; a.kh = op[W_KH]; a.kw = op[W_KW];
@@ -654,6 +660,7 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
         const int32_t *dt = &net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS];
         if (op[W_TYPE] == OP_STEMFUSED)
             net->macs_per_image += (double)(((unsigned long long)(unsigned)op[W_F_MACS_HI] << 32) | (unsigned)op[W_F_MACS_LO]);
+        if (op[W_TYPE] == OP_CONV && op[W_X_DST2] > 0) net->macs_per_image += (double)(unsigned)op[W_F_MACS_LO];   // the fused shortcut's share
         if (op[W_TYPE] == OP_CONV || op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_DWCONV)
             net->macs_per_image += (double)dt[T_H] * dt[T_W] * op[W_COUT] * (op[W_CIN] / std::max(1, op[W_GROUPS])) * op[W_KH] * op[W_KW];
     }

@@ -172,7 +172,11 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
         out.fused_groups = {"stem.fused": [c0.name, c1.name, c2.name, pool.name]}
         fused_upto = 4
 
-    for n in net.nodes[fused_upto:]:
+    skip = set()
+    for ni_, n in enumerate(net.nodes):
+        if ni_ < fused_upto or ni_ in skip:
+            continue
+        nxt = net.nodes[ni_ + 1] if ni_ + 1 < len(net.nodes) else None
         if n.kind == "conv" and n.src == "input":
             assert n.k == 3 and n.pad == 1 and n.groups == 1 and not n.pre_bn and n.res is None
             cout, (_, ho, wo) = n.cout, shp[n.name]
@@ -194,6 +198,53 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             dst = new_tensor(n.name, cout, ho, wo)
             emit(n.name, type=OP_STEM, src=-1, dst=dst, kh=3, kw=3, stride=n.stride, pad=1, cin=3, cout=cout,
                  act=ACT[n.act], woff=woff, wbytes=wbytes, boff=boff, soff=soff, wrows=cp)
+        elif (n.kind == "conv" and n.groups == 1 and n.pre_avgpool and not os.environ.get("FID_NO_DOWN_FUSE")
+              and nxt is not None and nxt.kind == "conv" and nxt.groups == 1 and nxt.src == n.src and nxt.k == 3 and nxt.stride == 2
+              and nxt.pad == 1 and nxt.res is None and not nxt.pre_bn and not n.pre_bn and not nxt.pre_avgpool
+              and nxt.act in ("none", "relu") and n.act == "none" and n.res is None and not n.res_up2 and not nxt.res_up2
+              and tensors[tid[n.src]][1] == 64 and _rup(n.cout, CPAD) == 96 and _rup(nxt.cout, CPAD) == 96
+              and shp[n.name][1:] == shp[nxt.name][1:]):
+            # The block's shortcut (2x2 average pool + 1x1 conv + BN = a 2x2 / stride-2 conv with W/4) reads the tensor the block's
+            # first conv (3x3 / stride 2 / pad 1) reads, and its window is taps (1..2, 1..2) of that conv's window: ONE launch of the
+            # stride-2 kernel with twice the couts and two outputs fetches the (large) input once instead of twice (csrc/conv_s2.hip,
+            # twelve waves: fragments 0..5 = the conv, 6..11 = the shortcut).  Op record: the conv's, with 192 weight / bias rows;
+            # word 20 = second output's tensor id + 1, 21 = its activation, 22 = padded couts of the first output, 26 / 27 = the MACs
+            # of the shortcut (cost accounting).
+            m = nxt
+            src_t = tensors[tid[n.src]]
+            cin_p = src_t[1]
+            _, ho, wo = shp[m.name]
+
+            def folded(c, W):
+                b = P[c.wname + ".bias"].astype(np.float64) if c.bias else np.zeros(c.cout)
+                if c.post_bn:
+                    a2, b2 = _bn_affine(P, c.wname + ".post_bn")
+                    W = W * a2[:, None, None, None]
+                    b = b * a2 + b2
+                return W, b
+            W1, b1 = folded(m, P[m.wname + ".weight"].astype(np.float64))                 # [cout, cin, 3, 3]
+            Wd = P[n.wname + ".weight"].astype(np.float64)                                # [cout, cin, 1, 1]
+            Wd = np.repeat(np.repeat(Wd, 2, axis=2), 2, axis=3) / 4.0                     # avgpool2 folded: 2x2 / stride 2
+            Wd, b2 = folded(n, Wd)
+            W2 = np.zeros((n.cout, n.cin, 3, 3))
+            W2[:, :, 1:3, 1:3] = Wd
+            Wp = np.concatenate([pack_weights(W1, cin_p, 96), pack_weights(W2, cin_p, 96)], axis=0)
+            woff, wbytes = blob.add(Wp)
+            bt = np.zeros((1, 192), dtype=np.float32)
+            bt[0, :m.cout] = b1
+            bt[0, 96:96 + n.cout] = b2
+            boff, _ = blob.add(bt)
+            dst2 = new_tensor(n.name, n.cout, ho, wo)
+            dst = new_tensor(m.name, m.cout, ho, wo)
+            emit(m.name, type=OP_CONV, src=tid[n.src], dst=dst, res=-1, kh=3, kw=3, stride=2, pad=1, cin=m.cin, cout=m.cout,
+                 act=ACT[m.act], flags=0, woff=woff, wbytes=wbytes, boff=boff, soff=-1, wrows=192)
+            ops[-1][20], ops[-1][21], ops[-1][22] = dst2 + 1, ACT[n.act], 96
+            macs2 = ho * wo * n.cout * n.cin * 4
+            assert macs2 < 2 ** 31
+            ops[-1][26], ops[-1][27] = macs2, 0
+            op_nodes[-1] = [n.name, m.name]
+            out.fused_groups[m.name] = [n.name, m.name]
+            skip.add(ni_ + 1)
         elif n.kind == "conv" and n.groups == 1:
             cin, cout = n.cin, n.cout
             _, ho, wo = shp[n.name]
@@ -335,21 +386,23 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
         return tensors[t][1] * tensors[t][2] * tensors[t][3] * (4 if tensors[t][4] == 1 else 2)
 
     for oi, rec in enumerate(ops):
-        d = rec[2]
-        need = nbytes(d)
-        if d in keep or not free:
-            slot_size.append(need)
-            slot_of[d] = len(slot_size) - 1
-        else:
-            best = min(free, key=lambda s: (slot_size[s] < need, abs(slot_size[s] - need)))
-            free.remove(best)
-            slot_size[best] = max(slot_size[best], need)
-            slot_of[d] = best
+        dsts = [rec[2]] + ([rec[20] - 1] if rec[0] == OP_CONV and rec[20] > 0 else [])    # (a fused shortcut + conv op writes two tensors)
+        for d in dsts:
+            need = nbytes(d)
+            if d in keep or not free:
+                slot_size.append(need)
+                slot_of[d] = len(slot_size) - 1
+            else:
+                best = min(free, key=lambda s: (slot_size[s] < need, abs(slot_size[s] - need)))
+                free.remove(best)
+                slot_size[best] = max(slot_size[best], need)
+                slot_of[d] = best
         for t in range(n_t):
-            if base[t] == t and slot_of[t] >= 0 and last_use[t] == oi and t not in keep and t != d:
+            if base[t] == t and slot_of[t] >= 0 and last_use[t] == oi and t not in keep and t not in dsts:
                 free.append(slot_of[t])
-        if last_use[d] < 0 and d not in keep:      # produced but never read
-            free.append(slot_of[d])
+        for d in dsts:
+            if last_use[d] < 0 and d not in keep:      # produced but never read
+                free.append(slot_of[d])
     for t in range(n_t):
         tensors[t][5] = slot_of[base[t]]
         if t in keep:
