@@ -113,3 +113,32 @@ def test_stride2_family(ctx, monkeypatch, gen, hw, cin, cout, res, batch):
     ref = np.transpose(ref, (0, 2, 3, 1))
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() / np.abs(ref).max() < 6e-3
+
+
+# the block shortcut (2x2 average pool + 1x1 conv) fused into the stride-2 conv that reads the same tensor (lower.py; conv_s2.hip DUAL):
+# fused and unfused lowering against the oracle, even and odd maps (partial tiles), with the conv2 that consumes both outputs
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("hw,planes,batch", [((64, 96), 88, 3), ((74, 50), 96, 2), ((34, 46), 88, 1)])
+def test_fused_shortcut_stride2(ctx, monkeypatch, fuse, hw, planes, batch):
+    from scrfd_arcface_facerecognition_amd import lower
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    if not fuse:
+        monkeypatch.setenv("FID_NO_DOWN_FUSE", "1")
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 64, act="relu"))
+    net.add(Conv("b.down", "s", 64, planes, k=1, stride=1, pad=0, pre_avgpool=True))
+    net.add(Conv("b.conv1", "s", 64, planes, stride=2, act="relu"))
+    net.add(Conv("b.conv2", "b.conv1", planes, planes, act="relu", res="b.down"))
+    net.outputs = ["b.conv2"]
+    P = archs.synth_params(net, seed=21)
+    low = lower.lower(net, P)
+    assert (len(low.ops) == 3) == fuse and any(int(r[20]) > 0 for r in low.ops if int(r[0]) == 2) == fuse
+    images = np.random.default_rng(8).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    cn.run(images)
+    got = {nm: cn.read(nm, batch) for nm in ("b.down", "b.conv1", "b.conv2")}
+    cn.close()
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean), keep=("b.down", "b.conv1", "b.conv2"))
+    for nm in got:
+        r = np.transpose(ref[nm], (0, 2, 3, 1))
+        assert np.abs(got[nm] - r).max() / np.abs(r).max() < 8e-3, nm
