@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     // resident variants: an item's finished tile is only STAGED (fp16, pixel rows) at the end of its last step; the 16-byte row stores
     // are issued one by one between the matrix rows of the next step, so the write burst of all CUs no longer sits between two steps
     // with every matrix pipe idle (measured on SCRFD layer1: 127 us with the epilogue, 99 with its stores dropped, 85 without it)
-    constexpr bool DEFER = WR_DEFER && NCH == 2;
+    constexpr bool DEFER = WR_DEFER && NCH == 2 && TH >= 14;    // (the store schedule below needs 15 matrix rows per column)
     constexpr bool DIRECT = WR_DIRECT && NCH == 0;               // streaming variants: 8-byte stores straight from the accumulator layout, no staging, no barriers
     constexpr int ST_I = (HR * 16 * CPX + NW * 64 - 1) / (NW * 64), EPI_ST = DIRECT ? NT * TH : NPASS * NT * ST_I;   // write-out instructions per wave and pass / item
     constexpr int RG = NCH > 0 ? 2 : (((TH == 16 && NT == 2) && HR > 4) ? 4 : HR);   // residual rows in registers at a time (resident variant: they come from LDS, just in time)
@@ -664,7 +664,7 @@ static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
         attr_lds = LDS;
     }
     // waves per CU by registers: > 168 VGPRs -> two per SIMD (8 per CU); the one-tile streaming variant stays below 168 -> three per SIMD
-    const int wg_per_cu = std::max(1, std::min((NT == 1 && NCH == 0 && TH == 14 ? 12 : 8) / NW, (160 * 1024) / LDS));
+    const int wg_per_cu = std::max(1, std::min((NT == 1 && NCH == 0 && TH <= 14 ? 12 : 8) / NW, (160 * 1024) / LDS));
     static const int wgpc_env = getenv("FID_WR_WGPC") ? atoi(getenv("FID_WR_WGPC")) : 0;
     const int grid = std::min(a.n_items, ctx->num_cus * (wgpc_env > 0 ? wgpc_env : wg_per_cu));
     hipLaunchKernelGGL((conv3x3_wr<TH, NT, NW, NCH, NS>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
@@ -688,7 +688,11 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
     // map in 3x3 tiles of 196 = 91 % useful pixels, where 16x16 tiles compute 48x48 for 69 %)
     auto padded = [&](int t) { return (long long)cdiv(c.H, t) * t * cdiv(c.W, t) * t; };
     const bool t14 = padded(14) * 16 <= padded(16) * 14;      // 14-wide tiles leave 2 of 16 lanes idle: require the pixel saving to cover that
-    const int TH = t14 ? 14 : 16;
+    // 10-row tiles for the maps neither edge fits (20x20: two tiles of 10 per side = 62 % useful lanes x rows, where 14 / 16-row tiles reach 45 / 39 %);
+    // instantiated for the one-tile variants those small maps take (resident, and streaming x 64 couts)
+    auto work = [&](int t) { return (double)padded(t) * 16.0 / t; };      // matrix rows x 16 lanes the tiling computes
+    const bool t10 = (resident || (nt == 1 && ring != 4)) && work(10) < 0.9 * std::min(work(14), work(16));
+    const int TH = t10 ? 10 : (t14 ? 14 : 16);
     WRArgs a{};
     a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
@@ -710,7 +714,7 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
     a.w_bytes = (unsigned)repack_bytes(2, c.Cout_p, c.Cin_p);
     if (resident) {
         const int key = (c.Cout_p / 16) * 10 + a.n_chunks;
-#define WR_RES(NWV, NCHV) (t14 ? wr_launch_t<14, 1, NWV, NCHV>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, NWV, NCHV>(ctx, a, a.n_tiles))
+#define WR_RES(NWV, NCHV) (t10 ? wr_launch_t<10, 1, NWV, NCHV>(ctx, a, a.n_tiles) : t14 ? wr_launch_t<14, 1, NWV, NCHV>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, NWV, NCHV>(ctx, a, a.n_tiles))
         switch (key) {
             case 42: return WR_RES(4, 2);
             case 43: return WR_RES(4, 3);
@@ -724,6 +728,7 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
     }
     if (nt == 2) return t14 ? wr_launch_t<14, 2, 8, 0>(ctx, a, a.n_tiles) : wr_launch_t<16, 2, 8, 0>(ctx, a, a.n_tiles);
     if (ring == 4) return t14 ? wr_launch_t<14, 1, 4, 0, 4>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, 4, 0, 4>(ctx, a, a.n_tiles);
+    if (t10) return wr_launch_t<10, 1, 4, 0>(ctx, a, a.n_tiles);
     return t14 ? wr_launch_t<14, 1, 4, 0>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, 4, 0>(ctx, a, a.n_tiles);
 }
 
