@@ -26,6 +26,13 @@ def test_face_analysis_get_matches_per_face_api():
         assert abs(np.linalg.norm(f.normed_embedding) - 1) < 2e-3
         assert np.abs(f.normed_embedding - f.embedding / np.linalg.norm(f.embedding)).max() < 1e-3
     assert app.best_face(frame).det_score == max(f.det_score for f in app.get(frame))
+    # ... and against the fp32 oracle, not only against our own per-face API: the embedding of every returned face from the oracle's
+    # warp + net on the same landmarks (detector decisions are oracle-checked on identical heads in test_gpu_models_api.py)
+    from oracle import pipeline as opipe
+    rec_net, rec_P = app.rec.session.net, app.rec.session.params
+    for f in faces:
+        ref, _ = opipe.embed(frame, f.kps, rec_net, rec_P)
+        assert 1 - float(ref @ f.embedding / np.linalg.norm(ref) / np.linalg.norm(f.embedding)) < 1e-3
 
 
 def test_stream_runner_equals_direct_steps():
@@ -45,7 +52,8 @@ def test_stream_runner_equals_direct_steps():
     rec_net = archs.mobilefacenet()
     det = CompiledNet(ctx, det_net, det_P, max_batch=B)
     rec = CompiledNet(ctx, rec_net, archs.synth_params(rec_net, 3), max_batch=B)
-    gal = Gallery(ctx, rng.standard_normal((20, 512)).astype(np.float32))
+    gal_np = rng.standard_normal((20, 512)).astype(np.float32)
+    gal = Gallery(ctx, gal_np)
     pipe = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=1)
     runner = StreamRunner(pipe, gal, (H, W), similarity_thresh=0.02)
     streamed = list(runner.run(iter(frames)))
@@ -62,6 +70,17 @@ def test_stream_runner_equals_direct_steps():
             assert len(a) == len(d)
             for fa, fd in zip(a, d):
                 assert np.array_equal(fa[0], fd[0]) and fa[1] == fd[1] and np.array_equal(fa[2], fd[2]) and fa[3] == fd[3] and fa[4] == fd[4]
+    # ... and the streamed results against the oracle (frame by frame, on the landmarks the stream reported): embedding -> similarity
+    from oracle import match as omatch, pipeline as opipe
+    rec_P = archs.synth_params(rec_net, 3)
+    checked = 0
+    for i in (0, 5, 9):                                               # one frame of each batch, the last from the ragged tail
+        for bbox, score, kps, name, sim in streamed[i]:
+            ref, _ = opipe.embed(frames[i], kps, rec_net, rec_P)
+            j, s_ref = omatch.gallery_scan(ref, gal_np, 0.02)
+            assert abs(s_ref - sim) < 2e-3
+            checked += 1
+    assert checked >= 1
     ctx.close()
 
 
