@@ -45,7 +45,8 @@ PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec); ~6.3 TB/s is what a streamin
 PROFILE_DIRS = ("r02", "r01")
 # persisted kernel plan (per conv op and batch size: kernel family / tile / split-K), keyed by device name and layer-table hash: with it
 # every box runs the same kernels and fp32 summation orders (bit-identical heads / embeddings) and nothing is timed at start-up.
-# Picks missing from the file are tuned as before (and appended to the box's copy).  FID_PLAN= (empty) switches it off.
+# The tracked file is loaded READ-ONLY (FID_PLAN_RO): picks missing from it are tuned as before but never written back by a bench
+# run (tools/make_plan.sh generates plans through FID_PLAN, which also appends).  FID_PLAN= (empty) switches the default plan off.
 DEFAULT_PLAN = os.path.join(ROOT, "plans", "mi355x.plan")
 _T0 = time.time()
 
@@ -234,8 +235,8 @@ def main():
                          "contexts/HIP streams so that the small kernels of one batch overlap another batch's")
     args = ap.parse_args()
 
-    if "FID_PLAN" not in os.environ and os.path.exists(DEFAULT_PLAN):
-        os.environ["FID_PLAN"] = DEFAULT_PLAN
+    if "FID_PLAN" not in os.environ and "FID_PLAN_RO" not in os.environ and os.path.exists(DEFAULT_PLAN):
+        os.environ["FID_PLAN_RO"] = DEFAULT_PLAN
     elif os.environ.get("FID_PLAN") == "":
         del os.environ["FID_PLAN"]
     rank = int(os.environ.get("RANK", "0"))
@@ -421,7 +422,8 @@ def main():
                                    + f"SCRFD-10G + ArcFace-R50, {B} synthetic 640x640 frames per GPU per step, "
                                    f"F={F} face/frame (max_num), {G}-entry gallery, random-init weights (seed 0)",
                        "frames_per_gpu": B, "faces_per_step": faces_total_step, "gallery": G,
-                       "kernel_plan": os.path.relpath(os.environ["FID_PLAN"], ROOT) if os.environ.get("FID_PLAN") else "autotuned at start-up",
+                       "kernel_plan": (os.path.relpath(os.environ.get("FID_PLAN") or os.environ["FID_PLAN_RO"], ROOT)
+                                       if (os.environ.get("FID_PLAN") or os.environ.get("FID_PLAN_RO")) else "autotuned at start-up"),
                        "parallelism": par + (f", {len(lanes)} batches in flight per GPU on separate HIP streams" if len(lanes) > 1 else "")},
             "repeats": len(repeats), "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in repeats],
             "ms_per_step_min": round(min(repeats) / args.steps * 1e3, 4),

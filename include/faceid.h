@@ -168,6 +168,12 @@ int fid_align_crops(fid_ctx *ctx, const uint8_t *frames_dev, int B, int H, int W
 
 /* ---- embeddings -> unit fp16 rows: the norm half of reference utils/helpers.py:120-123 ------ */
 int fid_l2_normalize_f16(fid_ctx *ctx, const float *emb_dev, int n, int dim, void *out_f16_dev);
+/* the same for the n = B * faces_per_frame face slots of a batch: slot (b, f) with f >= counts[b] holds no face (reference
+ * main.py:132 iterates detected faces only) and is written as an all-zero row, which scores 0 against every gallery row and so
+ * never matches (fid_match: idx -1, score 0).  The unit-embedding matrix thereby carries the face counts: after the all-gather of
+ * SURVEY.md 8e every rank can tell another rank's faces from its empty slots (zero row <=> no face). */
+int fid_l2_normalize_f16_slots(fid_ctx *ctx, const float *emb_dev, int n, int dim, const int32_t *counts_dev,
+                               int faces_per_frame, void *out_f16_dev);
 
 /* ---- gallery match: replaces the per-target python loop of reference main.py:136-142 --------
  * gallery: host fp32 [G, dim] raw embeddings (as build_targets collects them, main.py:102-103).

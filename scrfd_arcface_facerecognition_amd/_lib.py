@@ -68,6 +68,7 @@ SIGNATURES = {
     "fid_align_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fid_l2_normalize_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "fid_l2_normalize_f16_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "fid_gallery_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_void_pp]),
     "fid_gallery_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fid_gallery_info": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p]),

@@ -97,4 +97,8 @@ struct fid_ctx {
 namespace fid {
 // scratch arena `slot` with at least `bytes` bytes (grows by reallocating; contents undefined)
 int get_scratch(fid_ctx *ctx, int slot, size_t bytes, void **out);
+// hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for kernel `func` on the context's device.  The attribute is per device, so the
+// largest value set so far is remembered per (kernel, device) -- under a mutex: contexts on several devices and several host
+// threads launch the same kernels (a function-local static flag covered neither).
+int ensure_dyn_lds(fid_ctx *ctx, const void *func, int bytes);
 }  // namespace fid

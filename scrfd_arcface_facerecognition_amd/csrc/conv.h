@@ -30,6 +30,9 @@ struct ConvArgs {
     int act, flags, nsig;
     int res_H, res_W, res_Cp;
     int tiles_m, tiles_n;
+    int rev;       // walk the work items from the LAST to the first: the executor alternates the direction from layer to layer, so a layer starts on
+                   // the part of its input the producer wrote last -- still in the 256 MB Infinity Cache when the tensors (210 MB at 160x160x64
+                   // x 64 frames) are too large to survive a whole layer (kernels that do not implement it ignore the flag)
     int tm_fast;   // tile order: 0 = the cout tiles of a pixel tile are consecutive (convs: few cout tiles, weights stay in L2), 1 = the pixel tiles of a cout tile are (gallery match: few query tiles, each gallery tile is fetched from HBM once)
     unsigned in_bytes, w_bytes;
 };
@@ -48,6 +51,8 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split);
 #include <vector>
 std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split);
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan);
+// does the kernel `plan` names honour ConvArgs::rev?
+inline bool conv_walks_reverse(const ConvPlan &plan) { return plan.gen == 9; }
 // alternate weight packing a plan's kernel wants in ConvArgs::w_alt (0 = none); repack.hip builds it
 int plan_alt_kind(const ConvPlan &plan);
 size_t repack_bytes(int kind, int Cout_p, int Cin_p, int taps = 9);
@@ -89,6 +94,11 @@ int conv_s2_launch(fid_ctx *ctx, const ConvArgs &a);
 // through LDS; bm = 64 | 128 output pixels x bn = 128 | 256 couts per item; needs w_alt (kind 3)
 bool conv_gw_applicable(const ConvArgs &a);
 int conv_gw_launch(fid_ctx *ctx, const ConvArgs &a, int bm, int bn);
+
+// conv_bb.hip: a residual BasicBlock on 64 channels (conv3x3 + ReLU, conv3x3, + input, activation) in one launch; w1 / w2 are repack
+// kind 2 images packed by lower.py
+int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1, const void *w2, const float *b2, void *out, int B, int H, int W,
+                   int act2, int rev);
 
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,

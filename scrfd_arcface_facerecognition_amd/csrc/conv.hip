@@ -713,11 +713,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue(const ConvArgs a) {
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_cfg(fid_ctx *ctx, const ConvArgs &a) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * BK * 2;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv_mfma_kernel<BM, BN, BK, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (lds > 48 * 1024) FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_mfma_kernel<BM, BN, BK, WM, WN>, (int)((int)lds)));
     dim3 grid(a.tiles_m * a.tiles_n, a.ksplit);
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), lds, ctx->stream, a);
     return FID_OK;
@@ -727,11 +723,7 @@ template <int BM, int BN, int BK, int NS, int WM, int WN, bool PF = false>
 int launch_dma(fid_ctx *ctx, const ConvArgs &a) {
     constexpr int RPP = 4 * (64 / (BK / 8));
     constexpr size_t lds = (size_t)NS * (BM + (BN + RPP - 1) / RPP * RPP) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN, PF>, (int)((int)lds)));
     dim3 grid(a.tiles_m * a.tiles_n, a.ksplit);
     hipLaunchKernelGGL((conv_mfma_dma_kernel<BM, BN, BK, NS, WM, WN, PF>), grid, dim3(256), lds, ctx->stream, a);
     return FID_OK;
@@ -741,11 +733,7 @@ template <int BM, int BN, int BK, int NS, int WM, int WN>
 int launch_pcg(fid_ctx *ctx, const ConvArgs &a) {
     constexpr int RPP = 4 * (64 / (BK / 8));
     constexpr size_t lds = (size_t)NS * (BM + (BN + RPP - 1) / RPP * RPP) * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv_mfma_pc_kernel<BM, BN, BK, NS, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_mfma_pc_kernel<BM, BN, BK, NS, WM, WN>, (int)((int)lds)));
     dim3 grid(a.tiles_m * a.tiles_n, a.ksplit);
     hipLaunchKernelGGL((conv_mfma_pc_kernel<BM, BN, BK, NS, WM, WN>), grid, dim3(384), lds, ctx->stream, a);
     return FID_OK;

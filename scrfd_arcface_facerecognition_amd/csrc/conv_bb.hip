@@ -1,0 +1,298 @@
+// Fused residual BasicBlock on 64 channels:  out = act2( conv2( relu( conv1(x) + b1 ) ) + b2 + x ),  both convs 3x3 / stride 1 / pad 1, 64 -> 64
+// (SCRFD-10G layer1: three such blocks at 160x160 x 64 frames, reference models/scrfd.py:83 runs them inside session.run).
+//
+// Why: unfused, each of the two convs of such a block moves 420 / 630 MB per 64 frames (input + output, + the residual for the second)
+// through a CU-side memory path that takes ~9-10 B/clk/CU (profiles/r02: 105 / 138 us = 4.0 / 4.6 TB/s with the matrix pipes 46 % busy):
+// the layers are bound by bytes per CU, not by HBM and not by arithmetic.  Here the intermediate map never leaves the CU and the
+// residual is the centre of the input patch that is in LDS anyway: per 14x14 output tile 41.5 KB come in (18x18 haloed patch) and
+// 25 KB go out, against 2 x 41.5 + 32 (residual) + 2 x 32 KB per 16x16 tile for the two launches -- 2.1x fewer bytes per output pixel.
+//
+//   item  = one 14x14 OUTPUT tile x all 64 couts.  It needs conv1's result on the 16x16 region around it (one 16-pixel MFMA fragment
+//           per row, no partial fragments) and x on the 18x18 region around that: exactly conv3x3_wr's haloed patch.  The price is
+//           recompute: conv1 runs on 256 pixels and conv2 on 14 rows x 16 lanes per 196 stored pixels (1.22x the MACs of the pair).
+//   waves = 8: wave = (cout fragment cw = 0..3: couts 16cw..16cw+15) x (row group rg = 0..1: rows 8rg..8rg+7 of the intermediate tile,
+//           rows 7rg..7rg+6 of the output tile).  BOTH filter banks of a wave's 16 couts (2 convs x 2 chunks x 9 taps x 4 VGPRs = 144
+//           registers) stay in registers for the kernel's lifetime (repack.hip kind 2 layout, packed by lower.py).
+//   LDS   = two x-patch buffers (this item / the next one, fetched by LDS-DMA a whole item ahead) + the intermediate tile in patch
+//           layout (16x16 pixels x 2 chunks of 32 channels, outside-the-image pixels written as 0: they are conv2's zero padding) whose
+//           space doubles as the staging area of the finished tile (16-byte row stores, whole pixel rows).
+//   order = A: conv1 (2 chunks x 3 tap columns, row-sharing tap order of conv_chunked.hip) -> bias + ReLU -> LDS;  B: conv2 from LDS ->
+//           + bias + residual (read from the x patch) -> activation -> staging -> stores.  Four workgroup barriers per item.
+#include "conv.h"
+
+namespace fid {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned OOB = 0x7FFFFFF0u;
+constexpr int TO = 14;                                           // output tile edge
+constexpr int PW = 18, MW = 16;                                  // x patch / intermediate tile width in pixels
+constexpr int NPIX = PW * PW;                                    // 324
+constexpr int P_BLKS = (NPIX * 64 + 1023) / 1024, P_BYTES = P_BLKS * 1024;     // one 32-channel chunk of the patch: 21 KB
+constexpr int X_ITEM = 2 * P_BYTES;                              // both chunks
+constexpr int N_PIECES = 2 * P_BLKS;                             // 42 one-KB pieces per item
+constexpr int NWT = 8;
+constexpr int MAX_P = (N_PIECES + NWT - 1) / NWT;                // 6 per wave
+constexpr int MID_CH = MW * MW * 64, MID_BYTES = 2 * MID_CH;     // 32 KB
+constexpr int ROWB = 128, CPX = 8;                               // bytes / 16-byte chunks of a staged output pixel (64 couts)
+constexpr int ST_SLOTS = TO * 16 * CPX;                          // 16-byte slots of a staged tile (14 rows x 16 pixel columns)
+constexpr int ST_I = (ST_SLOTS + NWT * 64 - 1) / (NWT * 64);     // 4 stores per thread and item
+constexpr int OFF_X = 0, OFF_SPARE = 2 * X_ITEM, OFF_MID = OFF_SPARE + 1024, LDS_BYTES = OFF_MID + MID_BYTES + 512;
+static_assert(TO * 16 * ROWB <= MID_BYTES, "the staged tile lives in the intermediate tile's space");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ int swz64(int lin) { return (lin >> 1) & 3; }
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+struct BBArgs {
+    const void *in;
+    const void *w1, *w2;      // repack kind 2 images of the two filter banks (64 couts padded to a block of 128)
+    const float *b1, *b2;     // fp32 [64]
+    void *out;
+    int H, W;
+    int act2;                 // activation after the residual add (ACT_RELU | ACT_NONE)
+    int tiles_x, tiles_per_img, n_tiles;
+    FastDiv d_tpi, d_tx;
+    unsigned io_bytes;        // bytes of the input (= output) tensor
+    int rev;                  // ConvArgs::rev
+    int ablate;               // FID_BB_ABLATE timing experiments (wrong results): 1 no conv1, 2 no conv2, 4 no stores, 8 no patch fetch
+};
+
+__global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 3, rg = wave >> 2;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int bid = xcd_major_id(blockIdx.x, gridDim.x);
+    const int my_items = bid < a.n_tiles ? (a.n_tiles - 1 - bid) / gridDim.x + 1 : 0;
+    if (my_items == 0) return;
+
+    auto decode_tile = [&](int item, int &n, int &ty, int &tx) {
+        if (a.rev) item = a.n_tiles - 1 - item;
+        n = fastdiv(item, a.d_tpi);
+        const int r = item - n * a.tiles_per_img;
+        ty = fastdiv(r, a.d_tx); tx = r - ty * a.tiles_x;
+    };
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.io_bytes, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, a.io_bytes, 0x00020000);
+
+    // ---- my pieces of an item's patch: piece j = wave + 8k -> chunk j / 21, pixels 16 (j % 21) .. +15, four lanes per pixel
+    int p_pk[MAX_P];                                            // py | px << 8 | channel offset (halfs) << 16; py = 255: nothing to fetch
+#pragma unroll
+    for (int k = 0; k < MAX_P; k++) {
+        const int j = wave + NWT * k;
+        const int ch = j / P_BLKS, blk = j - ch * P_BLKS;
+        const int row = blk * 16 + (lane >> 2);
+        int py = row / PW;
+        const int px = row - py * PW;
+        if (row >= NPIX || j >= N_PIECES) py = 255;
+        p_pk[k] = py | (px << 8) | (((((lane & 3) ^ swz64(row)) * 8) + ch * 32) << 16);
+    }
+    auto issue_x = [&](int item, bool live, int buf) {          // exactly MAX_P instructions
+        int n, ty, tx;
+        decode_tile(live ? item : 0, n, ty, tx);
+        const int y0 = ty * TO - 2, x0 = tx * TO - 2;
+        char *dst = smem + OFF_X + buf * X_ITEM;
+#pragma unroll
+        for (int k = 0; k < MAX_P; k++) {
+            const int j = wave + NWT * k;
+            int pk = p_pk[k];
+            asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
+            const int py = pk & 255, iy = y0 + py, ix = x0 + ((pk >> 8) & 255);
+            const bool in = live && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 8);
+            const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * 64 + (pk >> 16)) * 2) : OOB;
+            char *d = j < N_PIECES ? dst + j * 1024 : smem + OFF_SPARE;   // surplus piece: zeros into the spare KB
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)d, 16, vo, 0, 0, 0);
+        }
+    };
+
+    issue_x(bid, true, 0);
+
+    // ---- both filter banks of my 16 couts: kind 2 = [chunk][cout fragment 0..7][dx][dy][lane] x 16 B
+    half8 w1[18], w2[18];                                       // [chunk * 9 + dy * 3 + dx]
+    {
+        const char *p1 = (const char *)a.w1 + cw * 9216 + lane * 16, *p2 = (const char *)a.w2 + cw * 9216 + lane * 16;
+#pragma unroll
+        for (int ck = 0; ck < 2; ck++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    w1[ck * 9 + dy * 3 + dx] = *(const half8 *)(p1 + ck * (8 * 9216) + dx * 3072 + dy * 1024);
+                    w2[ck * 9 + dy * 3 + dx] = *(const half8 *)(p2 + ck * (8 * 9216) + dx * 3072 + dy * 1024);
+                }
+    }
+    const f32x4 bias1 = *(const f32x4 *)(a.b1 + cw * 16 + fq * 4), bias2 = *(const f32x4 *)(a.b2 + cw * 16 + fq * 4);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 18; i++) asm volatile("" : "+v"(w1[i]), "+v"(w2[i]));
+
+    // ---- pixel fragment addresses (conv3x3_wr's scheme): lin = K + frow with K a compile-time constant per read; the swizzled 16-byte
+    // group of the lane is one of four, selected by K & 1 and (K >> 1) & 3.  The row groups start at patch rows 8 rg (x 18 pixels) and 7 rg
+    // (x 16 pixels): both multiples of 8 pixels, so they only add to the base.
+    int pbase[2][4];
+#pragma unroll
+    for (int par = 0; par < 2; par++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) pbase[par][c] = frow * 64 + ((fq ^ ((((frow + par) >> 1) + c) & 3)) << 4);
+
+    f32x4 acc[8];
+    constexpr int PD = 2;
+    // one 32-channel chunk of one conv: ROWS output rows of this wave from ROWS + 2 fragment rows x 3 tap columns
+    auto conv_chunk = [&](int base_off, auto rows_tag, auto pw_tag, const half8 *wv) {
+        constexpr int ROWS = decltype(rows_tag)::value, PWV = decltype(pw_tag)::value, PH = ROWS + 2;
+        int pb[2][4];
+#pragma unroll
+        for (int par = 0; par < 2; par++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                pb[par][c] = pbase[par][c] + base_off;
+                asm volatile("" : "+v"(pb[par][c]));
+            }
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            half8 pq[PD + 1];
+            auto load_p = [&](int r, int set) {
+                const int K = r * PWV + dx;
+                pq[set] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + K * 64));
+            };
+#pragma unroll
+            for (int r = 0; r < PD; r++) load_p(r, r % (PD + 1));
+#pragma unroll
+            for (int r = 0; r < PH; r++) {
+                if (r + PD < PH) load_p(r + PD, (r + PD) % (PD + 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    const int mi = r - dy;
+                    if (mi < 0 || mi >= ROWS) continue;
+                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[dy * 3 + dx], pq[r % (PD + 1)], acc[mi], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    using std::integral_constant;
+
+    int item = bid;
+    for (int it = 0; it < my_items; it++, item += gridDim.x) {
+        const int buf = it & 1;
+        // my pieces of this item's patch were requested a whole item ago; younger than them: the ST_I stores of the item before
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_I) : "memory");
+        raw_barrier();                                          // everybody's pieces; and everyone is done with the staged tile / the other patch buffer
+        issue_x(item + gridDim.x, it + 1 < my_items, buf ^ 1);
+        int n, ty, tx;
+        decode_tile(item, n, ty, tx);
+
+        // ================= A: conv1 on the 16x16 region (rows 8 rg .. 8 rg + 7 here) =================
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(a.ablate & 1)) {
+            const int xo = OFF_X + buf * X_ITEM + rg * (8 * PW * 64);
+            conv_chunk(xo, integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1);
+            conv_chunk(xo + P_BYTES, integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1 + 9);
+        }
+        {
+            // intermediate pixel (row 8 rg + i, column frow) = image pixel (ty*14 - 1 + row, tx*14 - 1 + frow); outside the image it is
+            // conv2's zero padding, NOT conv1 evaluated there
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int fr = lo & 15, q4 = lo >> 4;
+            const int gx = tx * TO - 1 + fr, gy0 = ty * TO - 1 + rg * 8;
+            const bool xin = (unsigned)gx < (unsigned)a.W;
+            char *mp = smem + OFF_MID + (cw >> 1) * MID_CH + (rg * 8 * MW + fr) * 64 + ((((cw & 1) * 2 + (q4 >> 1)) ^ swz64(fr)) << 4) + (q4 & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                half4 h = __builtin_elementwise_max(__builtin_convertvector(acc[i] + bias1, half4), half4{0, 0, 0, 0});
+                if (!(xin && (unsigned)(gy0 + i) < (unsigned)a.H)) h = half4{0, 0, 0, 0};
+                *(half4 *)(mp + i * (MW * 64)) = h;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();                                          // the intermediate tile is complete
+
+        // ================= B: conv2 on the 14x14 tile (rows 7 rg .. 7 rg + 6 here) =================
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(a.ablate & 2)) {
+            const int mo = OFF_MID + rg * (7 * MW * 64);
+            conv_chunk(mo, integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2);
+            conv_chunk(mo + MID_CH, integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2 + 9);
+        }
+        raw_barrier();                                          // everyone has read the intermediate tile: its space becomes the staging area
+        {
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int fr = lo & 15, q4 = lo >> 4;
+            // residual = x at the output pixel = patch pixel (row + 2, column + 2) of the chunk my couts live in
+            const int g0 = (cw & 1) * 2 + (q4 >> 1);
+            const char *xp = smem + OFF_X + buf * X_ITEM + (cw >> 1) * P_BYTES + (q4 & 1) * 8;
+            char *sp = smem + OFF_MID + fr * ROWB + (((cw * 2 + (q4 >> 1) + fr) % CPX) << 4) + (q4 & 1) * 8;   // chunk rotated by the pixel column
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const int r = rg * 7 + i, lin = (r + 2) * PW + fr + 2;
+                const half4 rs = *(const half4 *)(xp + lin * 64 + ((g0 ^ swz64(lin)) << 4));
+                f32x4 v = acc[i] + bias2 + __builtin_convertvector(rs, f32x4);
+                half4 h = __builtin_convertvector(v, half4);
+                if (a.act2 == ACT_RELU) h = __builtin_elementwise_max(h, half4{0, 0, 0, 0});
+                *(half4 *)(sp + r * (16 * ROWB)) = h;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();                                          // the tile is staged
+        {
+            // write-out: 16-byte slot g = i * 512 + thread = (pixel g / 8, chunk g % 8); 512 / 8 = 64 pixels = 4 tile rows per round
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int q0 = t2 >> 3, c = t2 & 7;
+            const int pr0 = q0 >> 4, pc = q0 & 15;
+            const int oy0 = ty * TO, ox = tx * TO + pc;
+            const bool okc = pc < TO && ox < a.W && !(a.ablate & 4);
+            const char *lsrc = smem + OFF_MID + q0 * ROWB + (((c + pc) % CPX) << 4);
+            const unsigned g0 = (unsigned)((((n * a.H + oy0 + pr0) * a.W + ox) * 64 + c * 8) * 2);
+            const unsigned rstride = (unsigned)(a.W * 64 * 2);
+#pragma unroll
+            for (int i = 0; i < ST_I; i++) {
+                const int row = 4 * i + pr0;
+                const bool ok = okc && row < TO && oy0 + row < a.H;
+                const u32x4 v = *(const u32x4 *)(lsrc + (row < TO ? i * (64 * ROWB) : 0));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, ok ? g0 + (unsigned)(4 * i) * rstride : OOB, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the surplus pieces target this workgroup's LDS: drain before exit
+}
+
+}  // namespace
+
+// x [B, H, W, 64] fp16 -> out [B, H, W, 64]; w1 / w2: repack kind 2 images (147 456 B each), b1 / b2 fp32 [64]
+int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1, const void *w2, const float *b2, void *out, int B, int H, int W,
+                   int act2, int rev) {
+    FID_REQUIRE(in && w1 && w2 && b1 && b2 && out && B > 0 && H >= 3 && W >= 3, "conv_bb: bad arguments");
+    FID_REQUIRE(act2 == ACT_RELU || act2 == ACT_NONE, "conv_bb: activation %d", act2);
+    BBArgs a{};
+    a.in = in; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2; a.out = out;
+    a.H = H; a.W = W; a.act2 = act2; a.rev = rev;
+    a.tiles_x = cdiv(W, TO);
+    a.tiles_per_img = a.tiles_x * cdiv(H, TO);
+    a.n_tiles = B * a.tiles_per_img;
+    a.d_tpi = fastdiv_make(a.tiles_per_img); a.d_tx = fastdiv_make(a.tiles_x);
+    const size_t bytes = (size_t)B * H * W * 64 * 2;
+    FID_REQUIRE(bytes <= OOB, "conv_bb: tensor larger than 2 GiB");
+    a.io_bytes = (unsigned)bytes;
+    static const int ablate = getenv("FID_BB_ABLATE") ? atoi(getenv("FID_BB_ABLATE")) : 0;
+    a.ablate = ablate;
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb, LDS_BYTES));
+    const int grid = std::min(a.n_tiles, ctx->num_cus);
+    hipLaunchKernelGGL(conv_bb, dim3(grid), dim3(NWT * 64), LDS_BYTES, ctx->stream, a);
+    FID_HIP(hipGetLastError());
+    return FID_OK;
+}
+
+}  // namespace fid

@@ -324,11 +324,7 @@ int launch_chunked(fid_ctx *ctx, const ChunkArgs &a) {
     constexpr int CB = 2 * NI * 16;
     constexpr size_t wb = (size_t)9 * CB * 64;
     constexpr size_t lds = 2 * wb + ((2 * wb + 3 * PATCH_BYTES <= 160 * 1024) ? 3 : 2) * PATCH_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_chunked<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_chunked<NI>, (int)((int)lds)));
     const int grid = std::min(a.n_items, ctx->num_cus);
     hipLaunchKernelGGL((conv3x3_chunked<NI>), dim3(grid), dim3(512), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());

@@ -275,11 +275,7 @@ int launch_direct(fid_ctx *ctx, const DirectArgs &a) {
     constexpr size_t scr = (size_t)8 * 64 * COUT_P * 2;
     constexpr size_t lds = base + scr <= 160 * 1024 ? base + scr : base;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_direct<CIN_P, COUT_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_direct<CIN_P, COUT_P>, (int)((int)lds)));
     const int grid = std::min((a.n_tiles + 1) / 2, ctx->num_cus);
     hipLaunchKernelGGL((conv3x3_direct<CIN_P, COUT_P>), dim3(grid), dim3(512), lds, ctx->stream, a);
     return FID_OK;

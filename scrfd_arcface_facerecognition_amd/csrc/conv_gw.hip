@@ -365,11 +365,7 @@ int gw_launch_t(fid_ctx *ctx, GWArgs &a) {
     a.tab_off = NS * BM * 64 * KC + NW * 2048;
     const int LDS = a.tab_off + (a.ncls + 1) * a.Cout_p * 4;
     FID_REQUIRE(LDS <= 160 * 1024, "conv_gw: %d bytes of LDS", LDS);
-    static int attr_lds = 0;
-    if (LDS > attr_lds) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv_gw<BM, NW, NS, WD, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_lds = LDS;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_gw<BM, NW, NS, WD, KC>, (int)(LDS)));
     const int wg_per_cu = std::max(1, std::min(8 / NW, (160 * 1024) / LDS));      // 8 waves per CU by registers
     static const int wgpc_env = getenv("FID_GW_WGPC") ? atoi(getenv("FID_GW_WGPC")) : 0;
     const int grid = std::min(a.n_items, ctx->num_cus * (wgpc_env > 0 ? wgpc_env : wg_per_cu));

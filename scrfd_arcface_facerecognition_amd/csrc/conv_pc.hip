@@ -667,11 +667,7 @@ __global__ void __launch_bounds__((N_CONS + N_PROD) * 64, 3) conv3x3_pc(const PC
 template <int NI, int WD, int PD, bool F32 = false, bool RS = false>
 int launch_pc(fid_ctx *ctx, const PCArgs &a) {
     constexpr size_t lds = (size_t)WD * 9 * 2 * NI * 16 * 64 + (size_t)PD * P_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pc<NI, WD, PD, F32, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_pc<NI, WD, PD, F32, RS>, (int)((int)lds)));
     const int grid = std::min(a.n_items, ctx->num_cus);
     hipLaunchKernelGGL((conv3x3_pc<NI, WD, PD, F32, RS>), dim3(grid), dim3((N_CONS + N_PROD) * 64), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());

@@ -439,11 +439,7 @@ int conv_pc2_launch(fid_ctx *ctx, const ConvArgs &c) {
     a.in_bytes = c.in_bytes; a.w_bytes = c.w_bytes;
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
     FID_REQUIRE(c.res == nullptr || c.res_Cp == c.Cout_p, "producer/consumer conv: residual with %d channels for %d outputs", c.res_Cp, c.Cout_p);
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pc2, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_pc2, (int)(LDS_BYTES)));
     const int grid = std::min(a.n_items, ctx->num_cus);
     hipLaunchKernelGGL(conv3x3_pc2, dim3(grid), dim3((N_CONS + N_PROD) * 64), LDS_BYTES, ctx->stream, a);
     FID_HIP(hipGetLastError());

@@ -368,11 +368,7 @@ int conv_pcr_launch(fid_ctx *ctx, const ConvArgs &c) {
     a.w_bytes = (unsigned)std::min<size_t>(c.w_bytes, (size_t)64 * 9 * 64 * 2);
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB");
     constexpr size_t lds = NCH * (size_t)W_BYTES + 2 * (size_t)T_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pcr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_pcr, (int)((int)lds)));
     const int grid = std::min(a.n_tiles, ctx->num_cus);
     hipLaunchKernelGGL(conv3x3_pcr, dim3(grid), dim3((N_CONS + N_PROD) * 64), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());

@@ -284,11 +284,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pp(const PPArgs a) {
 template <int NI>
 int launch_pp(fid_ctx *ctx, const PPArgs &a) {
     constexpr size_t lds = 2 * (size_t)9 * NI * 16 * 64 + 4 * P_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_pp<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_pp<NI>, (int)((int)lds)));
     const int grid = std::min(a.n_items, ctx->num_cus);
     hipLaunchKernelGGL((conv3x3_pp<NI>), dim3(grid), dim3(512), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());

@@ -359,11 +359,7 @@ bool conv_s2_applicable(const ConvArgs &a) {
 template <int NW, int NCH, bool DUAL = false>
 static int s2_launch_t(fid_ctx *ctx, const S2Args &a) {
     constexpr int LDS = 2 * P_BYTES + 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_s2<NW, NCH, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_s2<NW, NCH, DUAL>, (int)(LDS)));
     // workgroups per CU: two patch-slot pairs fit LDS; registers allow 12 waves per CU (<= 168 VGPRs) for two chunks, 8 for three
     const int wg_per_cu = std::max(1, std::min((NCH == 2 ? 12 : 8) / NW, 2));
     const int grid = std::min(a.n_tiles, ctx->num_cus * wg_per_cu);

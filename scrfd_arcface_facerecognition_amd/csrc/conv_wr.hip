@@ -59,6 +59,7 @@ struct WRArgs {
     FastDiv d_cblk, d_tpi, d_tx;
     unsigned in_bytes, out_bytes, w_bytes;
     int tab_off, ncls;   // LDS offset of the bias [ncls][Cout_p] + slope [Cout_p] fp32 tables; ncls = 9 with CF_BORDER else 1 (0: no bias)
+    int rev;      // walk the items from the last to the first (see ConvArgs::rev)
     int stagger;  // experiment: workgroups in the second half of the grid (the co-resident ones) start this many x 64 cycles late
     int ablate;   // FID_WR_ABLATE timing experiments (wrong results): 1 no step barrier, 2 no patch pieces, 4 no weight reloads, 8 no epilogue, 32 stores dropped, 64 no residual loads
 };
@@ -86,6 +87,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     const int frow = lane & 15, fq = lane >> 4;
 
     auto decode_item = [&](int item, int &pair, int &cb) {
+        if (a.rev) item = a.n_items - 1 - item;
         pair = fastdiv(item, a.d_cblk);
         cb = item - pair * a.n_cblk;
     };
@@ -466,11 +468,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             int lo2 = lane;
             asm volatile("" : "+v"(lo2));
             int n, ty, tx;
-            decode_tile(pend >= 0 && pend < a.n_tiles ? pend : 0, n, ty, tx);
+            const int ptile = (pend >= 0 && a.rev) ? a.n_items - 1 - pend : pend;     // (resident variant: item = tile)
+            decode_tile(ptile >= 0 && ptile < a.n_tiles ? ptile : 0, n, ty, tx);
             const int wl = wave * 64 + lo2, q0 = wl / CPX, c = wl - q0 * CPX;
             const int pr0 = q0 >> 4, pc = q0 & 15;
             const int oy0 = ty * TH, oxx = tx * TW + pc, co = c * 8;
-            const bool okc = pend >= 0 && pend < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p && !(a.ablate & 32);
+            const bool okc = ptile >= 0 && ptile < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p && !(a.ablate & 32);
             wo_src = sR + q0 * ROWB + (((c + pc) % CPX) << 4);
             wo_g0 = (unsigned)((((n * a.H + oy0 + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
             wo_rows = okc ? (a.H - oy0 < TH ? a.H - oy0 : TH) - pr0 : 0;      // 2 i < wo_rows: the lane may store row 2 i + pr0 of the tile
@@ -658,11 +661,7 @@ static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
     a.n_items = cdiv(n_tiles, NT) * a.n_cblk;
     a.d_cblk = fastdiv_make(a.n_cblk);
     FID_REQUIRE(NCH == 0 || (a.n_chunks == NCH && a.n_cblk == 1), "conv3x3_wr: resident variant %d x %d on %d chunks / %d cout blocks", NW * 16, NCH, a.n_chunks, a.n_cblk);
-    static int attr_lds = 0;
-    if (LDS > attr_lds) {
-        FID_HIP(hipFuncSetAttribute((const void *)conv3x3_wr<TH, NT, NW, NCH, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_lds = LDS;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_wr<TH, NT, NW, NCH, NS>, (int)(LDS)));
     // waves per CU by registers: > 168 VGPRs -> two per SIMD (8 per CU); the one-tile streaming variant stays below 168 -> three per SIMD
     const int wg_per_cu = std::max(1, std::min((NT == 1 && NCH == 0 && TH <= 14 ? 12 : 8) / NW, (160 * 1024) / LDS));
     static const int wgpc_env = getenv("FID_WR_WGPC") ? atoi(getenv("FID_WR_WGPC")) : 0;
@@ -696,7 +695,7 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
     WRArgs a{};
     a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
-    a.act = c.act; a.flags = c.flags;
+    a.act = c.act; a.flags = c.flags; a.rev = c.rev;
     static const int ablate = getenv("FID_WR_ABLATE") ? atoi(getenv("FID_WR_ABLATE")) : 0;
     a.ablate = ablate;
     static const int stagger = getenv("FID_WR_STAGGER") ? atoi(getenv("FID_WR_STAGGER")) : 0;

@@ -1,6 +1,8 @@
 // Context, device memory, events.  Plain HIP runtime calls; no torch anywhere in this library.
 #include "common.h"
 
+#include <map>
+
 namespace fid {
 static thread_local std::string g_err;
 void set_error(const char *fmt, ...) {
@@ -24,6 +26,17 @@ int get_scratch(fid_ctx *ctx, int slot, size_t bytes, void **out) {
         ctx->scratch_bytes[slot] = want;
     }
     *out = ctx->scratch[slot];
+    return FID_OK;
+}
+int ensure_dyn_lds(fid_ctx *ctx, const void *func, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> set_bytes;
+    std::lock_guard<std::mutex> lk(mu);
+    int &cur = set_bytes[std::make_pair(func, ctx->device)];
+    if (bytes > cur) {
+        FID_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        cur = bytes;
+    }
     return FID_OK;
 }
 }  // namespace fid

@@ -17,9 +17,20 @@ namespace fid {
 namespace {
 
 // one wavefront per row
-__global__ void __launch_bounds__(256) l2norm_rows(const float *__restrict__ x, int n, int dim, _Float16 *__restrict__ out) {
+// counts != NULL: row = face slot (frame row / F, face row % F); a slot at or past its frame's face count holds no face (its crop was
+// zero-filled by fid_align_crops) and is written as a ZERO row -- the gathered query matrix then carries the face counts itself
+// (a rank that receives it can tell faces from empty slots: SURVEY.md 8e; reference main.py:132 iterates detected faces only)
+__global__ void __launch_bounds__(256) l2norm_rows(const float *__restrict__ x, int n, int dim, _Float16 *__restrict__ out,
+                                                   const int *__restrict__ counts = nullptr, int F = 1) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n) return;
+    if (counts) {
+        const int b = row / F, f = row - b * F;
+        if (f >= counts[b]) {
+            for (int i = lane; i < dim; i += 64) out[(size_t)row * dim + i] = (_Float16)0.f;
+            return;
+        }
+    }
     const float *r = x + (size_t)row * dim;
     float ss = 0.f;
     for (int i = lane; i < dim; i += 64) ss = fmaf(r[i], r[i], ss);
@@ -151,7 +162,17 @@ extern "C" {
 int fid_l2_normalize_f16(fid_ctx *ctx, const float *emb_dev, int n, int dim, void *out_f16_dev) {
     FID_REQUIRE(ctx && emb_dev && out_f16_dev && n > 0 && dim > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    hipLaunchKernelGGL(fid::l2norm_rows, dim3(fid::cdiv(n, 4)), dim3(256), 0, ctx->stream, emb_dev, n, dim, (_Float16 *)out_f16_dev);
+    hipLaunchKernelGGL(fid::l2norm_rows, dim3(fid::cdiv(n, 4)), dim3(256), 0, ctx->stream, emb_dev, n, dim, (_Float16 *)out_f16_dev, (const int *)nullptr, 1);
+    FID_HIP(hipGetLastError());
+    return FID_OK;
+}
+
+int fid_l2_normalize_f16_slots(fid_ctx *ctx, const float *emb_dev, int n, int dim, const int32_t *counts_dev, int faces_per_frame,
+                               void *out_f16_dev) {
+    FID_REQUIRE(ctx && emb_dev && out_f16_dev && counts_dev && n > 0 && dim > 0 && faces_per_frame > 0 && n % faces_per_frame == 0, "bad args");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipLaunchKernelGGL(fid::l2norm_rows, dim3(fid::cdiv(n, 4)), dim3(256), 0, ctx->stream, emb_dev, n, dim, (_Float16 *)out_f16_dev,
+                       (const int *)counts_dev, faces_per_frame);
     FID_HIP(hipGetLastError());
     return FID_OK;
 }
@@ -169,7 +190,7 @@ int fid_gallery_create(fid_ctx *ctx, const float *gallery, int G, int dim, fid_g
     FID_HIP(hipMalloc(&tmp, (size_t)G * dim * 4));
     FID_HIP(hipMemsetAsync(g->unit_f16, 0, (size_t)g->Gp * dim * 2, ctx->stream));
     FID_HIP(hipMemcpyAsync(tmp, gallery, (size_t)G * dim * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(fid::l2norm_rows, dim3(fid::cdiv(G, 4)), dim3(256), 0, ctx->stream, (const float *)tmp, G, dim, (_Float16 *)g->unit_f16);
+    hipLaunchKernelGGL(fid::l2norm_rows, dim3(fid::cdiv(G, 4)), dim3(256), 0, ctx->stream, (const float *)tmp, G, dim, (_Float16 *)g->unit_f16, (const int *)nullptr, 1);
     FID_HIP(hipStreamSynchronize(ctx->stream));
     FID_HIP(hipFree(tmp));
     *out = g;

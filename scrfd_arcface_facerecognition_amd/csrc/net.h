@@ -4,7 +4,7 @@
 
 namespace fid {
 
-enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5 };
+enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6 };
 
 // int32 word indices inside one op record (FID_OP_WORDS = 32 words)
 enum : int {
@@ -30,6 +30,9 @@ enum : int {
     // OP_STEMFUSED (stem_fused.hip): blob offsets of the three convs' packed weights / biases
     W_F_W0 = 20, W_F_B0 = 21, W_F_W1 = 22, W_F_B1 = 23, W_F_W2 = 24, W_F_B2 = 25,
     W_F_MACS_LO = 26, W_F_MACS_HI = 27,   // algorithmic MACs per image of the fused group (cost accounting)
+    // OP_BBLOCK (conv_bb.hip; lower.py): blob offsets of the two convs' weights in repack kind 2 order and of their biases; W_ACT = the activation
+    // after the residual add; W_F_MACS_* = MACs per image of both convs
+    W_B_W1 = 20, W_B_B1 = 21, W_B_W2 = 22, W_B_B2 = 23,
     // OP_CONV fused with the block's shortcut (lower.py; conv_s2.hip DUAL): second output's tensor id + 1 (0: plain conv), its activation,
     // padded couts of the first output; W_F_MACS_LO then holds the shortcut's MACs per image
     W_X_DST2 = 20, W_X_ACT2 = 21, W_X_COUT1P = 22,

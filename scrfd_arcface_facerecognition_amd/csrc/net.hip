@@ -9,6 +9,7 @@
 #include "net.h"
 
 #include <map>
+#include <set>
 
 struct fid_net {
     int n_ops = 0, n_tensors = 0, in_h = 0, in_w = 0, max_batch = 0;
@@ -21,6 +22,9 @@ struct fid_net {
     int sub_batch = 0;   // images per depth-first pass (0 = whole batch)
     // autotuned kernel choice per conv op and batch size: tuned[op][batch]
     std::vector<std::map<int, fid::ConvPlan>> tuned;
+    std::vector<char> tdir;              // per tensor: 1 = last written from the last work item to the first (ConvArgs::rev)
+    int alternate = 1;                   // FID_NO_REV=1: every layer walks forward
+    std::vector<std::set<int>> plan_ok;   // batches whose tuned[op] entry has been checked against this library's candidates (or was tuned here)
     int autotune = 1;
     size_t partial_cap = 0;
     hipEvent_t *prof_events = nullptr;
@@ -283,6 +287,9 @@ TensorView view(const fid_net *net, int id, int first = 0) {
     return TensorView{(char *)net->slots[t[T_SLOT]] + per_image * first, t[T_C], t[T_CP], t[T_H], t[T_W], t[T_DTYPE]};
 }
 
+// bump when conv_candidates() / the kernels' tile meanings change: it is hashed into the plan key
+constexpr int FID_PLAN_REV = 3;
+
 unsigned long long fnv1a(const void *p, size_t n, unsigned long long h = 1469598103934665603ull) {
     const unsigned char *b = (const unsigned char *)p;
     for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
@@ -309,13 +316,32 @@ int plan_load(fid_net *net, const char *path, int *n_loaded) {
                        &c.partial_bytes) != 11)
                 continue;
             if (h != net->table_hash || net->device_key != dev || oi < 0 || oi >= net->n_ops || batch <= 0) continue;
-            net->tuned[oi][batch] = c;      // later lines win (a re-tuned pick is appended)
+            net->tuned[oi][batch] = c;      // later lines win (a re-tuned pick is appended); checked against the candidates at first use
+            net->plan_ok[oi].erase(batch);
             n++;
         }
         fclose(f);
     }
     if (n_loaded) *n_loaded = n;
     return FID_OK;
+}
+
+bool same_kernel(const ConvPlan &x, const ConvPlan &y) {
+    return x.gen == y.gen && x.bm == y.bm && x.bn == y.bn && x.bk == y.bk && x.ksplit == y.ksplit && x.ns == y.ns;
+}
+
+// repacked weight copies of op `oi` that no tuned plan of the op uses any more (the autotuner builds one per packing it times)
+void drop_unused_alt_weights(fid_ctx *ctx, fid_net *net, int oi) {
+    bool used[4] = {false, false, false, false};
+    for (const auto &kv : net->tuned[oi]) used[plan_alt_kind(kv.second) & 3] = true;
+    bool synced = false;
+    for (auto it = net->alt_w.begin(); it != net->alt_w.end();) {
+        if (it->first.first == oi && !used[it->first.second & 3]) {
+            if (!synced) { (void)hipStreamSynchronize(ctx->stream); synced = true; }
+            (void)hipFree(it->second);
+            it = net->alt_w.erase(it);
+        } else ++it;
+    }
 }
 
 // ConvArgs::w_alt for `plan` (built on the context's stream the first time an op needs that packing)
@@ -328,7 +354,8 @@ int set_alt_weights(fid_ctx *ctx, fid_net *net, int oi, ConvArgs &a, const ConvP
     if (it == net->alt_w.end()) {
         void *p = nullptr;
         FID_HIP(hipMalloc(&p, repack_bytes(kind, a.w_rows, a.Cin_p, a.kh * a.kw) + 256));      // (w_rows = Cout_p except for the fused shortcut + conv op)
-        FID_TRY(repack_weights(ctx, kind, a.w, p, a.w_rows, a.Cin_p, a.kh * a.kw));
+        const int rc = repack_weights(ctx, kind, a.w, p, a.w_rows, a.Cin_p, a.kh * a.kw);
+        if (rc != FID_OK) { (void)hipFree(p); return rc; }
         it = net->alt_w.emplace(key, p).first;
     }
     a.w_alt = it->second;
@@ -343,6 +370,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
     images += (size_t)first * net->in_h * net->in_w * 3;
     const float *bias = op[W_BOFF] >= 0 ? (const float *)(blob + op[W_BOFF]) : nullptr;
     const float *slope = op[W_SOFF] >= 0 ? (const float *)(blob + op[W_SOFF]) : nullptr;
+    if (op[W_TYPE] != OP_CONV && op[W_TYPE] != OP_BBLOCK) net->tdir[op[W_DST]] = 0;
     switch (op[W_TYPE]) {
         case OP_STEM: {
             const long long total = (long long)batch * dst.H * dst.W;
@@ -403,9 +431,24 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             a.in_bytes = (unsigned)((size_t)batch * src.H * src.W * src.Cp * 2);
             a.w_bytes = (unsigned)op[W_WBYTES];
             a.partial = (float *)partial_ws;
+            a.rev = net->alternate && op[W_SRC] >= 0 && !net->tdir[op[W_SRC]];
             ConvPlan plan;
             auto &cache = net->tuned[oi];
             auto it = cache.find(batch);
+            if (it != cache.end() && !net->plan_ok[oi].count(batch)) {
+                // a pick that came from a plan file (FID_PLAN / fid_net_plan_load) is text: before its first use it must name one of
+                // THIS library's candidates for the op (another revision's candidate set, a hand-edited line) and its split-K
+                // workspace -- recomputed here, not taken from the file -- must fit the scratch this run sized
+                bool ok = false;
+                for (const ConvPlan &c : conv_candidates(a, ctx->num_cus, true))
+                    if (same_kernel(c, it->second) && c.partial_bytes <= net->partial_cap && (c.ksplit == 1 || partial_ws)) { it->second = c; ok = true; break; }
+                if (!ok && it->second.ksplit == 1) {             // (conv_plan's heuristic pick is not always in the candidate list)
+                    const ConvPlan h = conv_plan(a, ctx->num_cus, false);
+                    if (same_kernel(h, it->second)) { it->second = h; ok = true; }
+                }
+                if (ok) net->plan_ok[oi].insert(batch);
+                else { cache.erase(it); it = cache.end(); }
+            }
             if (it != cache.end()) {
                 plan = it->second;
             } else if (net->autotune && partial_ws) {
@@ -456,6 +499,8 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 (void)hipEventDestroy(e0);
                 (void)hipEventDestroy(e1);
                 cache[batch] = plan;
+                net->plan_ok[oi].insert(batch);
+                drop_unused_alt_weights(ctx, net, oi);
                 if (!net->plan_path.empty()) {                      // persist the pick (one O_APPEND line)
                     if (FILE *pf = fopen(net->plan_path.c_str(), "a")) {
                         char line[512];
@@ -473,12 +518,23 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             }
             FID_TRY(set_alt_weights(ctx, net, oi, a, plan));
             FID_TRY(conv_launch(ctx, a, plan));
+            net->tdir[op[W_DST]] = (char)(a.rev && conv_walks_reverse(plan));
+            if (op[W_X_DST2] > 0) net->tdir[op[W_X_DST2] - 1] = net->tdir[op[W_DST]];
             break;
         }
         case OP_STEMFUSED: {
             FID_TRY(stem_fused_launch(ctx, images, batch, net->in_h, net->in_w, blob + op[W_F_W0], (const float *)(blob + op[W_F_B0]),
                                       blob + op[W_F_W1], (const float *)(blob + op[W_F_B1]), blob + op[W_F_W2],
                                       (const float *)(blob + op[W_F_B2]), dst.ptr, dst.Cp));
+            break;
+        }
+        case OP_BBLOCK: {
+            const TensorView src = view(net, op[W_SRC], first);
+            FID_REQUIRE(src.Cp == 64 && dst.Cp == 64 && src.H == dst.H && src.W == dst.W && src.dtype == 0 && dst.dtype == 0, "op %d: bad fused block record", oi);
+            const int rev = net->alternate && !net->tdir[op[W_SRC]];
+            FID_TRY(conv_bb_launch(ctx, src.ptr, blob + op[W_B_W1], (const float *)(blob + op[W_B_B1]), blob + op[W_B_W2],
+                                   (const float *)(blob + op[W_B_B2]), dst.ptr, batch, dst.H, dst.W, op[W_ACT], rev));
+            net->tdir[op[W_DST]] = (char)rev;
             break;
         }
         case OP_MAXPOOL: {
@@ -514,10 +570,9 @@ size_t partial_need(fid_ctx *ctx, fid_net *net, int batch) {
         a.Cin_p = src.Cp; a.Cout_p = dst.Cp; a.kh = op[W_KH]; a.kw = op[W_KW];
         a.M = batch * dst.H * dst.W; a.flags = op[W_FLAGS];
         need = std::max(need, conv_plan(a, ctx->num_cus, true).partial_bytes);
-        if (net->autotune) {
-            a.H = src.H; a.W = src.W; a.Ho = dst.H; a.Wo = dst.W; a.stride = op[W_STRIDE]; a.pad = op[W_PAD]; a.w_rows = op[W_WROWS];
-            for (const ConvPlan &c : conv_candidates(a, ctx->num_cus, true)) need = std::max(need, c.partial_bytes);
-        }
+        // every candidate's workspace, whether or not this net autotunes: a loaded plan may name any of them
+        a.H = src.H; a.W = src.W; a.Ho = dst.H; a.Wo = dst.W; a.stride = op[W_STRIDE]; a.pad = op[W_PAD]; a.w_rows = op[W_WROWS];
+        for (const ConvPlan &c : conv_candidates(a, ctx->num_cus, true)) need = std::max(need, c.partial_bytes);
     }
     return std::max<size_t>(need, 256);
 }
@@ -651,14 +706,16 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
         const bool ok = op[W_DST] >= 0 && op[W_DST] < n_tensors && op[W_SRC] >= -1 && op[W_SRC] < n_tensors &&
                         op[W_RES] >= -1 && op[W_RES] < n_tensors && op[W_WOFF] >= -1 &&
                         (op[W_WOFF] < 0 || (size_t)op[W_WOFF] + (size_t)op[W_WBYTES] <= blob_bytes) &&
-                        (op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_STEMFUSED) == (op[W_SRC] == -1);
+                        (op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_STEMFUSED) == (op[W_SRC] == -1) &&
+                        (op[W_TYPE] != OP_BBLOCK || (op[W_B_W1] >= 0 && op[W_B_W2] >= 0 && (size_t)std::max(op[W_B_W1], op[W_B_W2]) + 147456 <= blob_bytes &&
+                                                     op[W_B_B1] >= 0 && op[W_B_B2] >= 0 && (size_t)std::max(op[W_B_B1], op[W_B_B2]) + 256 <= blob_bytes));
         if (!ok) {
             delete net;
             set_error("op %d: bad record", oi);
             return FID_E_INVALID;
         }
         const int32_t *dt = &net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS];
-        if (op[W_TYPE] == OP_STEMFUSED)
+        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK)
             net->macs_per_image += (double)(((unsigned long long)(unsigned)op[W_F_MACS_HI] << 32) | (unsigned)op[W_F_MACS_LO]);
         if (op[W_TYPE] == OP_CONV && op[W_X_DST2] > 0) net->macs_per_image += (double)(unsigned)op[W_F_MACS_LO];   // the fused shortcut's share
         if (op[W_TYPE] == OP_CONV || op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_DWCONV)
@@ -681,6 +738,9 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
     if (const char *e = getenv("FID_AUTOTUNE")) net->autotune = atoi(e);
     if (const char *e = getenv("FID_GRAPH")) net->graphs = atoi(e);
     net->tuned.resize(n_ops);
+    net->plan_ok.resize(n_ops);
+    net->tdir.assign(n_tensors, 0);
+    if (getenv("FID_NO_REV")) net->alternate = 0;
     {
         hipDeviceProp_t prop;
         FID_HIP(hipGetDeviceProperties(&prop, ctx->device));
@@ -692,10 +752,14 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
         unsigned long long h = fnv1a(net->ops.data(), net->ops.size() * sizeof(int32_t));
         h = fnv1a(net->tensors.data(), net->tensors.size() * sizeof(int32_t), h);
         h = fnv1a(&blob_bytes, sizeof(blob_bytes), h);
+        const int rev = FID_PLAN_REV;                         // candidate-set revision: plans of another library revision do not match
+        h = fnv1a(&rev, sizeof(rev), h);
         net->table_hash = h;
     }
-    if (const char *e = getenv("FID_PLAN")) {
+    if (const char *e = getenv("FID_PLAN")) {                 // load + append every new pick (plan generation: tools/make_plan.sh)
         net->plan_path = e;
+        (void)plan_load(net, e, nullptr);
+    } else if (const char *e = getenv("FID_PLAN_RO")) {        // load only: a tracked plan file is never written by a run (bench.py)
         (void)plan_load(net, e, nullptr);
     }
     *out = net;

@@ -319,8 +319,7 @@ int fid_scrfd_set_candidate_capacity(fid_ctx *ctx, int cand_cap) {
     FID_REQUIRE(cand_cap >= 16 && cand_cap <= 16800, "cand_cap %d outside [16, 16800]", cand_cap);
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->cand_cap = cand_cap;
-    const size_t lds = fid::nms_lds_bytes(cand_cap, nullptr);
-    FID_HIP(hipFuncSetAttribute((const void *)nms_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FID_TRY(fid::ensure_dyn_lds(ctx, (const void *)nms_select, (int)fid::nms_lds_bytes(cand_cap, nullptr)));
     return FID_OK;
 }
 
@@ -342,10 +341,7 @@ int fid_scrfd_postprocess(fid_ctx *ctx, const float *const head_dev[9], const in
         hv.batch_stride[k] = batch_stride[k];
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (ctx->cand_cap > 2048) {
-        const size_t lds = fid::nms_lds_bytes(ctx->cand_cap, nullptr);
-        FID_HIP(hipFuncSetAttribute((const void *)nms_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    FID_TRY(fid::ensure_dyn_lds(ctx, (const void *)nms_select, (int)fid::nms_lds_bytes(ctx->cand_cap, nullptr)));   // (above 64 KB from ~2000 candidates on)
     return fid::scrfd_postprocess_launch(ctx, hv, B, in_h, in_w, num_anchors, img_h, img_w, conf_thres, iou_thres, max_num,
                                          metric, det_dev, kps_dev, counts_dev, cap);
 }
@@ -435,8 +431,7 @@ int fid_nms(fid_ctx *ctx, const float *dets_dev, int K, float iou_thres, int32_t
     hipLaunchKernelGGL(rank_scatter, dim3(fid::cdiv(cc, 256), 1), dim3(256), 0, ctx->stream, cand_count, keys, data, sorted, cc);
     int n_box = 0;
     const size_t lds = fid::nms_lds_bytes(cc, &n_box);
-    FID_HIP(hipFuncSetAttribute((const void *)nms_select, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)std::max<size_t>(lds, fid::nms_lds_bytes(ctx->cand_cap, nullptr))));
+    FID_TRY(fid::ensure_dyn_lds(ctx, (const void *)nms_select, (int)std::max<size_t>(lds, fid::nms_lds_bytes(ctx->cand_cap, nullptr))));
     hipLaunchKernelGGL(nms_select, dim3(1), dim3(512), lds, ctx->stream, cand_count, sorted, cc, iou_thres, 0, 0, 1, 1,
                        (float *)nullptr, (float *)nullptr, count_dev, K, keep_dev, ctx->status_dev + 4, n_box < 0 ? -n_box : n_box, n_box > 0);
     FID_HIP(hipGetLastError());

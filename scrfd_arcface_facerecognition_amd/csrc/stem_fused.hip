@@ -347,11 +347,7 @@ int launch_stem(fid_ctx *ctx, const StemArgs &a) {
     constexpr int INP_BYTES = ((RI * 132) * 2 + 2 + 255) / 256 * 256;
     constexpr size_t lds = INP_BYTES + ((N0 + 15) / 16 * 16) * 64 + ((N1 + 15) / 16 * 16) * 64 + ((N2 + 15) / 16 * 16) * (C2P * 2) +
                            32 * 64 + 9 * C1P * 64 + 9 * C2P * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FID_HIP(hipFuncSetAttribute((const void *)scrfd_stem_fused<C2P, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)scrfd_stem_fused<C2P, NW>, (int)((int)lds)));
     const int grid = std::min(a.n_tiles, ctx->num_cus);
     hipLaunchKernelGGL((scrfd_stem_fused<C2P, NW>), dim3(grid), dim3(NW * 64), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());

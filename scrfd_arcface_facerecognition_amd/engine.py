@@ -81,6 +81,29 @@ class CompiledNet:
         check(self.ctx.lib.fid_net_plan_load(self.handle, str(path).encode(), C.byref(n)))
         return n.value
 
+    def plans(self) -> List[dict]:
+        """the kernel pick of every conv op that has run so far: [{op, name, batch, gen, bm, bn, bk, ksplit, ns}] (parsed from
+        fid_net_plan_save's lines; tests use it to check WHICH kernel family produced a result)"""
+        import os
+        import tempfile
+        fd, path = tempfile.mkstemp(suffix=".plan")
+        os.close(fd)
+        try:
+            self.save_plan(path)
+            out = []
+            with open(path) as f:
+                for line in f:
+                    parts = line.rstrip("\n").split("|")
+                    if len(parts) != 5:
+                        continue
+                    v = [int(x) for x in parts[4].split()]
+                    oi = int(parts[2])
+                    out.append(dict(op=oi, name=self.low.op_names[oi], batch=int(parts[3]), gen=v[0], bm=v[1], bn=v[2], bk=v[3],
+                                    ksplit=v[4], ns=v[5]))
+            return out
+        finally:
+            os.unlink(path)
+
     def macs_per_image(self) -> float:
         v = C.c_double()
         check(self.ctx.lib.fid_net_macs(self.handle, C.byref(v)))

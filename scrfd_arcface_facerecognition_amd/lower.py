@@ -8,6 +8,8 @@ models/scrfd.py:59-62, models/arcface.py:18-21), written down:
     shift into a 9-entry border-class bias table (a border pixel's missing taps contribute no shift);
   * AvgPool(2)+Conv1x1 ("avg_down" shortcut) becomes one 2x2/stride-2 conv with weights/4;
   * nearest-2x upsample + add (PAFPN top-down) and the residual add become epilogue flags;
+  * a residual BasicBlock on 64 (padded) channels -- conv3x3+ReLU, conv3x3, + block input, activation -- becomes ONE op whose
+    intermediate map never leaves the CU (csrc/conv_bb.hip; FID_NO_BB_FUSE=1 keeps the two convs);
   * the three SCRFD output convs of a level become one conv with 2+8+20 output channels, sigmoid on
     the first two, bbox scale folded in, fp32 output;
   * blobFromImage's (x-127.5)*scale and BGR->RGB swap are folded into the first conv's weights;
@@ -26,7 +28,7 @@ import numpy as np
 from .archs import BN_EPS, Net, infer_shapes
 
 OP_WORDS, TENSOR_WORDS = 32, 8
-OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED = 1, 2, 3, 4, 5
+OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK = 1, 2, 3, 4, 5, 6
 ACT = {"none": 0, "relu": 1, "prelu": 2}
 CF_RES_UP2, CF_BORDER, CF_OUT_F32 = 1, 2, 4
 CPAD = 32
@@ -114,6 +116,16 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
         if not np.isfinite(h).all():
             raise ValueError("weights overflow fp16")
         return h
+
+    def repack_kind2(Wp):
+        """fp16 [cout_p <= 128][9][cin_p] -> csrc/repack.hip kind 2 (conv3x3_wr's MFMA A fragments in lane order):
+        [32-channel chunk][cout fragment 0..7][dx][dy][lane][8 halfs], lane = (channel group of 8) * 16 + (cout & 15)"""
+        cout_p, taps, cin_p = Wp.shape
+        assert taps == 9 and cout_p <= 128 and cin_p % 32 == 0
+        full = np.zeros((128, 9, cin_p), dtype=np.float16)
+        full[:cout_p] = Wp
+        x = full.reshape(8, 16, 3, 3, cin_p // 32, 4, 8)          # [cf][cout & 15][dy][dx][ck][group][e]
+        return np.ascontiguousarray(x.transpose(4, 0, 3, 2, 5, 1, 6))   # [ck][cf][dx][dy][group][cout & 15][e]
 
     def padded(vec, n, fill=0.0):
         o = np.full(n, fill, dtype=np.float32)
@@ -215,17 +227,17 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             cin_p = src_t[1]
             _, ho, wo = shp[m.name]
 
-            def folded(c, W):
+            def folded_w(c, W):
                 b = P[c.wname + ".bias"].astype(np.float64) if c.bias else np.zeros(c.cout)
                 if c.post_bn:
                     a2, b2 = _bn_affine(P, c.wname + ".post_bn")
                     W = W * a2[:, None, None, None]
                     b = b * a2 + b2
                 return W, b
-            W1, b1 = folded(m, P[m.wname + ".weight"].astype(np.float64))                 # [cout, cin, 3, 3]
+            W1, b1 = folded_w(m, P[m.wname + ".weight"].astype(np.float64))                 # [cout, cin, 3, 3]
             Wd = P[n.wname + ".weight"].astype(np.float64)                                # [cout, cin, 1, 1]
             Wd = np.repeat(np.repeat(Wd, 2, axis=2), 2, axis=3) / 4.0                     # avgpool2 folded: 2x2 / stride 2
-            Wd, b2 = folded(n, Wd)
+            Wd, b2 = folded_w(n, Wd)
             W2 = np.zeros((n.cout, n.cin, 3, 3))
             W2[:, :, 1:3, 1:3] = Wd
             Wp = np.concatenate([pack_weights(W1, cin_p, 96), pack_weights(W2, cin_p, 96)], axis=0)
@@ -243,6 +255,40 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             assert macs2 < 2 ** 31
             ops[-1][26], ops[-1][27] = macs2, 0
             op_nodes[-1] = [n.name, m.name]
+            out.fused_groups[m.name] = [n.name, m.name]
+            skip.add(ni_ + 1)
+        elif (n.kind == "conv" and n.groups == 1 and not os.environ.get("FID_NO_BB_FUSE") and nxt is not None and nxt.kind == "conv"
+              and nxt.groups == 1 and n.k == 3 and nxt.k == 3 and n.stride == 1 and nxt.stride == 1 and n.pad == 1 and nxt.pad == 1
+              and n.act == "relu" and nxt.act in ("relu", "none") and n.res is None and nxt.res == n.src and nxt.src == n.name
+              and not n.res_up2 and not nxt.res_up2 and not n.pre_bn and not nxt.pre_bn and not n.pre_avgpool and not nxt.pre_avgpool
+              and n.src != "input" and tensors[tid[n.src]][1] == 64 and tensors[tid[n.src]][4] == 0 and _rup(n.cout, CPAD) == 64
+              and _rup(nxt.cout, CPAD) == 64 and n.name not in net.outputs
+              and not any(getattr(x, "src", None) == n.name or getattr(x, "res", None) == n.name for x in net.nodes if x is not nxt)):
+            # A residual BasicBlock on 64 stored channels (SCRFD-10G layer1): conv1 + ReLU -> conv2 -> + block input -> activation as ONE
+            # launch (csrc/conv_bb.hip): conv1's output only feeds conv2, so it is never materialised.  Both filter banks go into the blob
+            # in the register-fragment order the kernel loads (repack.hip kind 2).
+            m = nxt
+            W1, b1 = folded(n)
+            W2, b2 = folded(m)
+            offs = [blob.add(repack_kind2(pack_weights(W1, 64, 64)))[0], blob.add(padded(b1, 64))[0],
+                    blob.add(repack_kind2(pack_weights(W2, 64, 64)))[0], blob.add(padded(b2, 64))[0]]
+            _, ho, wo = shp[m.name]
+            dst = new_tensor(m.name, m.cout, ho, wo)
+            rec = [0] * OP_WORDS
+            rec[0], rec[1], rec[2], rec[3] = OP_BBLOCK, tid[n.src], dst, -1
+            rec[4] = rec[5] = 3
+            rec[6], rec[7] = 1, 1
+            rec[8], rec[9], rec[10] = n.cin, m.cout, ACT[m.act]
+            rec[13] = rec[15] = rec[16] = -1
+            rec[18] = 1
+            rec[20:24] = offs
+            macs = ho * wo * 9 * (n.cout * n.cin + m.cout * m.cin)
+            rec[26], rec[27] = macs & 0xFFFFFFFF, macs >> 32
+            if rec[26] >= 2 ** 31:
+                rec[26] -= 2 ** 32
+            ops.append(rec)
+            op_names.append(m.name)
+            op_nodes.append([n.name, m.name])
             out.fused_groups[m.name] = [n.name, m.name]
             skip.add(ni_ + 1)
         elif n.kind == "conv" and n.groups == 1:

@@ -74,8 +74,10 @@ class FacePipeline:
                                            self.post.cap, self.F, C.c_void_p(self.crops.ptr), None))
         self.rec.run_device(self.crops, self.n_slots)
         emb_ptr, _, _ = self.rec.tensor(self.rec.low.outputs[0])
-        check(self.ctx.lib.fid_l2_normalize_f16(self.ctx.handle, C.c_void_p(emb_ptr), self.n_slots, self.emb_dim,
-                                                _lib._ptr(self.q)))
+        # empty face slots (f >= counts[b]) become all-zero unit rows: they never match, and the matrix the all-gather moves tells
+        # every rank which slots of the other ranks hold faces (gathered_face_counts)
+        check(self.ctx.lib.fid_l2_normalize_f16_slots(self.ctx.handle, C.c_void_p(emb_ptr), self.n_slots, self.emb_dim,
+                                                      C.c_void_p(self.post.counts.ptr), self.F, _lib._ptr(self.q)))
 
     def match(self, gallery: Gallery, thresh: float, q=None, n=None, idx=None, score=None):
         gallery.match_device(self.q if q is None else q, self.n_slots if n is None else n, thresh,
@@ -291,6 +293,14 @@ class Communicator:
             self.handle = None
 
 
+def gathered_face_counts(q_all: np.ndarray, frames_total: int, faces_per_frame: int) -> np.ndarray:
+    """Face count of every frame of the WHOLE batch from the gathered unit-embedding matrix [frames_total * F, 512] (host copy):
+    a slot holds a face iff its row is not all zero (fid_l2_normalize_f16_slots), slots fill from f = 0 -- so the one collective of
+    SURVEY.md 8e also carries `counts[]` and idx_all / score_all can be read like the reference's per-face loop (main.py:132)."""
+    valid = (np.asarray(q_all).reshape(frames_total, faces_per_frame, -1) != 0).any(axis=2)
+    return valid.sum(axis=1).astype(np.int32)
+
+
 def _slice_ptr(buf, row0: int, row_bytes: int):
     """device address of row `row0` of a 2-D device buffer (torch tensor / DeviceBuffer / raw int)"""
     base = buf.data_ptr() if hasattr(buf, "data_ptr") else (buf.ptr if hasattr(buf, "ptr") else int(buf))
@@ -318,11 +328,25 @@ def run_step_distributed(pipe, frames_dev, H, W, gallery, thresh, q_local, q_all
                  world*n queries (fid_match_keys), a second tiny all-gather exchanges the packed (score, index) keys
                  (keys_local [world*n] u64 -> keys_all [world, world*n]), fid_match_merge takes the arg-max.
     """
-    pipe.detect(frames_dev, H, W)
-    pipe.embed(frames_dev, H, W)            # writes q_local (pipe.q aliases it)
-    dist.all_gather_into_tensor(q_all, q_local)
     r, world = dist.get_rank(), dist.get_world_size()
     n = pipe.n_slots
+
+    def rows(buf):                                   # entries of a result / key buffer (torch tensor, DeviceBuffer, numpy array)
+        if buf is None:
+            return 0
+        return int(np.prod(tuple(buf.shape))) if hasattr(buf, "shape") else int(buf.nbytes // buf.itemsize)
+
+    # the scopes that write world*n results must be given buffers of that size: falling back to pipe.idx / pipe.score (n entries)
+    # would overrun them at world > 1 (a one-rank group may use them: world*n == n)
+    if match_scope == "all" and idx_all is None and score_all is None and world == 1:
+        idx_all, score_all = pipe.idx, pipe.score
+    if match_scope in ("all", "sharded") and (rows(idx_all) < world * n or rows(score_all) < world * n):
+        raise ValueError(f"match_scope={match_scope!r} writes {world * n} results: pass idx_all / score_all with at least that many entries")
+    if match_scope == "sharded" and (rows(keys_local) < world * n or rows(keys_all) < world * world * n or gallery_total <= 0):
+        raise ValueError("match_scope='sharded' needs keys_local [world*n], keys_all [world*world*n] (uint64) and gallery_total")
+    pipe.detect(frames_dev, H, W)
+    pipe.embed(frames_dev, H, W)            # writes q_local (pipe.q aliases it); empty face slots are zero rows
+    dist.all_gather_into_tensor(q_all, q_local)
     if match_scope == "own":
         pipe.match(gallery, thresh, q=_slice_ptr(q_all, r * n, 512 * 2), n=n)
     elif match_scope == "all":

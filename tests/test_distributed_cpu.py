@@ -71,6 +71,9 @@ class OraclePipe:
         score[:n] = torch.from_numpy(np.where(ok, s, 0).astype(np.float32))
 
 
+F = 2          # face slots per frame in the ragged test
+
+
 def _worker(rank, world, port, q_np, gal, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -97,10 +100,21 @@ def _worker(rank, world, port, q_np, gal, out_dir):
                              score_all=score_all, match_scope=scope, **kw)
         assert pipe.calls == ["detect", "embed"]
         assert torch.equal(q_all, torch.from_numpy(q_np))            # every rank holds all embeddings, in frame order
+        # ... and with them the face counts of EVERY rank's frames (empty slots travel as zero rows)
+        from scrfd_arcface_facerecognition_amd.pipeline import gathered_face_counts
+        res[f"{scope}_counts"] = gathered_face_counts(q_all.numpy(), N // F, F)
         if scope == "own":
             res[f"{scope}_idx"], res[f"{scope}_score"] = pipe.idx.numpy().copy(), pipe.score.numpy().copy()
         else:
             res[f"{scope}_idx"], res[f"{scope}_score"] = idx_all.numpy().copy(), score_all.numpy().copy()
+    # the pre-round-3 call shape (no idx_all / score_all) would write world*n results into the n-entry pipe.idx: refused at world > 1
+    pipe = OraclePipe(q_np[lo:hi], torch.zeros((n, 512), dtype=torch.float16), None)
+    try:
+        run_step_distributed(pipe, None, 640, 640, gal, 0.4, torch.zeros((n, 512), dtype=torch.float16), torch.zeros((N, 512), dtype=torch.float16), dist)
+        res["positional_raises"] = False
+    except ValueError:
+        res["positional_raises"] = True
+    assert pipe.calls == []                                          # refused before any device work
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), lo=lo, hi=hi, **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -124,14 +138,26 @@ def test_two_rank_step_all_scopes(tmp_path):
     emb = rng.standard_normal((world * per_rank, 512)).astype(np.float32)
     for i in range(0, len(emb), 2):
         emb[i] = gal[rng.integers(0, 51)] + 0.5 * rng.standard_normal(512).astype(np.float32)
-    emb[2] = gal[40]
+    emb[4] = gal[40]
     emb[12] = gal[50] + 0.1 * rng.standard_normal(512).astype(np.float32)   # best row = the last row of the last shard
-    q = (emb / np.linalg.norm(emb, axis=1, keepdims=True)).astype(np.float16)       # what fid_l2_normalize_f16 emits
+    q = (emb / np.linalg.norm(emb, axis=1, keepdims=True)).astype(np.float16)       # what fid_l2_normalize_f16_slots emits ...
+    # ... for ragged frames (F = 2 slots each): frame 1 has no face, frames 3 and 6 one face -- their empty slots are zero rows
+    counts = np.full(world * per_rank // F, F, dtype=np.int32)
+    counts[1], counts[3], counts[6] = 0, 1, 1
+    for b, c in enumerate(counts):
+        q[b * F + c:(b + 1) * F] = 0
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, q, gal, str(tmp_path)), nprocs=world, join=True)
-    ref_idx, ref_score = match.match_batch(q.astype(np.float32), gal, 0.4)
-    assert ref_idx[2] == 7 and ref_idx[12] == 50
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref_idx, ref_score = match.match_batch(q.astype(np.float32), gal, 0.4)
+    assert ref_idx[4] == 7 and ref_idx[12] == 50
+    empty = np.array([f >= counts[b] for b in range(len(counts)) for f in range(F)])
+    assert (ref_idx[empty] == -1).all() and (ref_score[empty] == 0).all()            # an empty slot is never a match
     outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    for r in range(world):
+        assert bool(outs[r]["positional_raises"])
+        for scope in ("all", "own", "sharded"):
+            assert np.array_equal(outs[r][f"{scope}_counts"], counts), (r, scope)    # every rank recovers every frame's face count
     for r in range(world):                                          # "all" and "sharded": every rank holds the whole batch
         for scope in ("all", "sharded"):
             assert np.array_equal(outs[r][f"{scope}_idx"], ref_idx), (r, scope)

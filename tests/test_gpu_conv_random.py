@@ -1,9 +1,11 @@
-"""GPU: seeded random layer shapes through the halo-patch kernel families (producer/consumer, two-tile, resident-weight,
-channel-chunked) against the register-staged implicit GEMM (generation 1) on the same weights and frames: the families must
-agree to fp16 summation-order noise on every shape they accept (odd maps, partial tiles, odd tile counts, single images)."""
+"""GPU: seeded random layer shapes through every conv kernel family that takes stride-1 layers (register-staged implicit GEMM,
+channel-chunked, producer/consumer, resident-weight, two-tile, weights-in-registers conv3x3_wr in its four variants, weights-in-
+registers implicit GEMM conv_gw) against the fp32 CPU oracle on the same weights and frames -- odd maps, partial tiles, odd tile
+counts, single images.  A family that takes none of the case's layers is not counted (the plan read-back tells)."""
 import numpy as np
 import pytest
 
+from oracle import align, nets as onets
 from scrfd_arcface_facerecognition_amd import archs
 from scrfd_arcface_facerecognition_amd.archs import Conv, Net
 
@@ -38,23 +40,46 @@ def build(hw, c1, c2, acts, res, pre_bn):
     return net
 
 
+# (FID_FORCE_GEN, FID_FORCE_NS) per family; conv3x3_wr: NS 1 / 2 = one / two tiles per item, 3 = resident weights, 4 = four-slot ring
+FAMILIES = [(1, None), (3, None), (5, None), (7, None), (8, None), (9, 1), (9, 2), (9, 3), (9, 4), (11, None)]
+
+
+def took(plans, gen, ns):
+    def hit(p):
+        if p["gen"] != gen:
+            return False
+        if gen != 9 or ns is None:
+            return True
+        return {1: p["ns"] not in (1, 4) and p["bm"] // 256 == 1, 2: p["ns"] not in (1, 4) and p["bm"] // 256 == 2, 3: p["ns"] == 1, 4: p["ns"] == 4}[ns]
+    return [p["name"] for p in plans if hit(p)]
+
+
 @pytest.mark.parametrize("seed", range(24))
-def test_families_agree(ctx, monkeypatch, seed):
+def test_families_vs_oracle(ctx, monkeypatch, seed):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     rng = np.random.default_rng(1000 + seed)
     hw, c1, c2, batch, acts, res, pre_bn = random_case(rng)
     net = build(hw, c1, c2, acts, res, pre_bn)
     P = archs.synth_params(net, seed=seed)
     images = rng.integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
-    outs = {}
-    for gen in (1, 3, 5, 7, 8):
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["c"]
+    ref = np.transpose(ref, (0, 2, 3, 1))
+    scale = np.abs(ref).max() + 1e-6
+    n_checked = 0
+    for gen, ns in FAMILIES:
         monkeypatch.setenv("FID_FORCE_GEN", str(gen))
+        if ns is None:
+            monkeypatch.delenv("FID_FORCE_NS", raising=False)
+        else:
+            monkeypatch.setenv("FID_FORCE_NS", str(ns))
         cn = CompiledNet(ctx, net, P, max_batch=batch)
         cn.run(images)
-        outs[gen] = cn.read("c", batch).astype(np.float32)
+        o = cn.read("c", batch).astype(np.float32)
+        ran = took(cn.plans(), gen, ns)
         cn.close()
-    ref = outs[1]
-    scale = np.abs(ref).max() + 1e-6
-    for gen, o in outs.items():
-        assert np.isfinite(o).all(), (gen, hw, c1, c2, batch)
-        assert np.abs(o - ref).max() / scale < 4e-3, (gen, hw, c1, c2, batch, acts, res, pre_bn)
+        if not ran:
+            continue
+        n_checked += 1
+        assert np.isfinite(o).all(), (gen, ns, hw, c1, c2, batch)
+        assert np.abs(o - ref).max() / scale < 8e-3, (gen, ns, ran, hw, c1, c2, batch, acts, res, pre_bn)
+    assert n_checked >= 2, (hw, c1, c2)

@@ -92,3 +92,63 @@ def test_native_communicator_single_rank_and_all_scopes():
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), scope
     comm.close()
     ctx.close()
+
+
+def test_empty_face_slots_travel_as_zero_rows():
+    """SURVEY.md 8e / reference main.py:132 (only detected faces are matched): the unit-embedding matrix the all-gather moves
+    carries the face counts -- slot (b, f) with f >= counts[b] is an all-zero row (fid_l2_normalize_f16_slots), never matches
+    (idx -1, score 0) and gathered_face_counts recovers counts[] from the matrix alone.  Checked on synthetic counts through the
+    C-ABI and on a pipeline step whose batch holds frames with fewer faces than slots."""
+    import ctypes as C
+    from scrfd_arcface_facerecognition_amd import archs
+    from scrfd_arcface_facerecognition_amd._lib import Context, check
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
+    from scrfd_arcface_facerecognition_amd.pipeline import FacePipeline, calibrate_detector_bias, gathered_face_counts
+    ctx = Context(0)
+    rng = np.random.default_rng(12)
+    B, F = 5, 3
+    emb = rng.standard_normal((B * F, 512)).astype(np.float32)
+    counts = np.array([0, 1, 3, 2, 5], dtype=np.int32)
+    gal_host = rng.standard_normal((77, 512)).astype(np.float32)
+    gal_host[5] = emb[3]                                                # frame 1, slot 0: a face that matches
+    gal_host[9] = emb[5]                                                # frame 1, slot 2: an EMPTY slot whose embedding would match
+    gal = Gallery(ctx, gal_host)
+    e_dev, c_dev = ctx.to_device(emb), ctx.to_device(counts)
+    q_plain, q = ctx.empty((B * F, 512), np.float16), ctx.empty((B * F, 512), np.float16)
+    check(ctx.lib.fid_l2_normalize_f16(ctx.handle, C.c_void_p(e_dev.ptr), B * F, 512, C.c_void_p(q_plain.ptr)))
+    check(ctx.lib.fid_l2_normalize_f16_slots(ctx.handle, C.c_void_p(e_dev.ptr), B * F, 512, C.c_void_p(c_dev.ptr), F, C.c_void_p(q.ptr)))
+    ctx.sync()
+    qp, qs = q_plain.download(), q.download()
+    valid = np.array([f < counts[b] for b in range(B) for f in range(F)])
+    assert np.array_equal(qs[valid], qp[valid]) and (qs[~valid] == 0).all() and (np.abs(qs[valid]).max(axis=1) > 0).all()
+    assert np.array_equal(gathered_face_counts(qs, B, F), np.minimum(counts, F))
+    idx, score = ctx.empty((B * F,), np.int32), ctx.empty((B * F,), np.float32)
+    gal.match_device(q, B * F, 0.05, idx, score)
+    ctx.sync()
+    i, s = idx.download(), score.download()
+    assert (i[~valid] == -1).all() and (s[~valid] == 0).all() and i[3] == 5 and i[5] == -1
+
+    # a pipeline step: frames 1 and 3 are featureless (constant colour); whatever the detector makes of them, slots past a frame's
+    # face count must be zero rows / "Unknown", the others unit rows, and the matrix must give back the counts
+    B, F = 4, 2
+    frames = rng.integers(0, 256, (B, 320, 320, 3), dtype=np.uint8)
+    det_net = archs.scrfd_500m((320, 320))
+    det_P, _ = calibrate_detector_bias(ctx, det_net, archs.synth_params(det_net, 2), frames, target=32, max_batch=B)
+    frames[1] = 0
+    frames[3] = 255
+    rec_net = archs.mobilefacenet()
+    det = CompiledNet(ctx, det_net, det_P, max_batch=B)
+    rec = CompiledNet(ctx, rec_net, archs.synth_params(rec_net, 2), max_batch=B * F)
+    pipe = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=F)
+    pipe.run_step(ctx.to_device(frames), 320, 320, gal, 0.0)
+    ctx.sync()
+    cnt = np.minimum(pipe.post.counts.download()[:B], F)
+    qh = pipe.q.download()
+    assert np.array_equal(gathered_face_counts(qh, B, F), cnt)
+    vis = np.array([f < cnt[b] for b in range(B) for f in range(F)])
+    assert (pipe.idx.download()[~vis] == -1).all() and (pipe.score.download()[~vis] == 0).all()
+    nrm = np.linalg.norm(qh.astype(np.float32), axis=1)
+    assert np.allclose(nrm[vis], 1.0, atol=2e-3) and (nrm[~vis] == 0).all()
+    res = pipe.results(gal)
+    assert [len(r) for r in res] == list(cnt)
+    ctx.close()

@@ -14,11 +14,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("plan", [None, "plans/mi355x.plan"])
+def test_full_size_properties(plan, monkeypatch):
+    """plan = None: the kernels a fresh autotune picks on this box; plan = the committed file: the kernels bench.py's headline number
+    times (bench.py loads it the same way, read-only) -- their detector heads and embeddings meet the oracle too."""
+    import os
+    from conftest import ROOT
     from scrfd_arcface_facerecognition_amd import archs
     from scrfd_arcface_facerecognition_amd._lib import Context, check
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
     from scrfd_arcface_facerecognition_amd.pipeline import FacePipeline, calibrate_detector_bias
+    monkeypatch.delenv("FID_PLAN", raising=False)
+    if plan is None:
+        monkeypatch.delenv("FID_PLAN_RO", raising=False)
+    else:
+        monkeypatch.setenv("FID_PLAN_RO", os.path.join(ROOT, plan))
     ctx = Context(0)
     B, F = 64, 1
     rng = np.random.default_rng(77)
@@ -30,6 +40,12 @@ def test_full_size_properties():
     rec_P = archs.synth_params(rec_net, 0)
     det = CompiledNet(ctx, det_net, det_P, max_batch=B)
     rec = CompiledNet(ctx, rec_net, rec_P, max_batch=B * F)
+    if plan is not None:
+        # the file's picks must really be installed (same device name, CU count and layer tables as the plan was made on): a plan that
+        # does not apply would silently re-test the fresh autotune
+        n_det, n_rec = det.load_plan(os.path.join(ROOT, plan)), rec.load_plan(os.path.join(ROOT, plan))
+        if n_det == 0 or n_rec == 0:
+            pytest.skip(f"{plan} holds no picks for this device / library revision ({n_det} detector, {n_rec} recogniser lines)")
     pipe = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=F)
     gal0 = Gallery(ctx, rng.standard_normal((1000, 512)).astype(np.float32))
 

@@ -125,3 +125,33 @@ def test_forward_decode_goldens(ctx):
             assert np.array_equal(r[m, 4:5], g[p + f"scores{lv}"])
             assert np.array_equal(r[m, 0:4], g[p + f"bboxes{lv}"])
             assert np.array_equal(r[m, 5:15].reshape(-1, 5, 2), g[p + f"kpss{lv}"])
+
+
+def test_tied_scores_follow_the_one_rule(ctx):
+    """Duplicate scores inside one stride and across strides (tests/test_oracle_golden.py::tied_heads pins the rule on the oracle:
+    detect -> score descending, flat anchor ascending; of two overlapping equal-score candidates the lower anchor survives; max_num
+    prefers the later of equal areas; nms() alone walks ties in descending index order): the device must agree bit for bit."""
+    from test_oracle_golden import tied_heads
+    outs, cand = tied_heads()
+    for max_num, metric in ((0, 0), (3, 0), (4, 1)):
+        (det, kps), = run_post(ctx, [outs], (640, 640), max_num, metric)
+        odet, okps = pp.detect_from_heads(outs, (640, 640), max_num=max_num, metric="max" if metric == 0 else "d")
+        assert np.array_equal(det, odet) and np.array_equal(kps, okps), (max_num, metric)
+    # a batch whose frames differ only by which candidates tie
+    outs2, _ = tied_heads(seed=6, n_groups=2)
+    res = run_post(ctx, [outs, outs2, outs], (640, 640))
+    for heads, (det, kps) in zip((outs, outs2, outs), res):
+        odet, okps = pp.detect_from_heads(heads, (640, 640))
+        assert np.array_equal(det, odet) and np.array_equal(kps, okps)
+    # fid_nms on a plain det array with tied scores
+    from scrfd_arcface_facerecognition_amd._lib import check
+    rng = np.random.default_rng(2)
+    K = 300
+    xy = rng.uniform(0, 600, (K, 2)).astype(np.float32)
+    wh = rng.uniform(10, 60, (K, 2)).astype(np.float32)
+    dets = np.concatenate([xy, xy + wh, rng.choice(np.float32([0.9, 0.8, 0.7, 0.6]), (K, 1))], axis=1).astype(np.float32)
+    d = ctx.to_device(dets)
+    keep, cnt = ctx.empty((K,), np.int32), ctx.empty((1,), np.int32)
+    check(ctx.lib.fid_nms(ctx.handle, C.c_void_p(d.ptr), K, 0.4, C.c_void_p(keep.ptr), C.c_void_p(cnt.ptr)))
+    n = int(cnt.download()[0])
+    assert [int(k) for k in keep.download()[:n]] == [int(k) for k in pp.nms(dets, 0.4)]

@@ -127,3 +127,74 @@ def test_crop_bytes_f32_vs_f64_transform():
     print(f"crop bytes differing between the fp32-derived and the fp64 transform: {flipped} of {total} ({frac:.2e}); "
           f"worst face {worst} of 37632 bytes; {faces_changed} of {len(g['M'])} faces touched; largest step {max_step}")
     assert frac < 2e-3 and worst < 1200
+
+
+def tied_heads(seed=5, n_groups=6):
+    """Dense SCRFD heads (640x640, 2 anchors) whose candidates hold DUPLICATED scores -- inside one stride and across strides
+    (saturated sigmoid outputs of fp16 towers do tie) -- with boxes far enough apart that NMS keeps every one of them, plus two
+    tied candidates that overlap (one must suppress the other).  Returns (outs[9], flat anchor ids of the candidates)."""
+    rng = np.random.default_rng(seed)
+    ns = [12800, 3200, 800]
+    total = sum(ns)
+    scores = np.full(total, 0.125, dtype=np.float32)
+    bbox = np.zeros((total, 4), dtype=np.float32)
+    kps = np.zeros((total, 10), dtype=np.float32)
+    # anchors on a coarse grid of the stride-8 map (pixel pitch 80 = 640 px / 8 cells: boxes of ~24 px never touch), both anchors of
+    # some cells, and anchors of the stride-16 / stride-32 maps at other places
+    cells8 = [(y * 80 + x) * 2 for y in range(5, 75, 10) for x in range(5, 75, 10)]
+    cand = list(rng.choice(cells8, 20, replace=False)) + [12800 + (y * 40 + x) * 2 for y, x in ((3, 3), (3, 30), (30, 3))] \
+        + [16000 + (y * 20 + x) * 2 + 1 for y, x in ((1, 18), (18, 1))]
+    vals = np.float32([0.984375, 0.75, 0.99951171875, 0.5625, 0.875, 0.6875])[:n_groups]
+    for i, a in enumerate(cand):
+        scores[a] = vals[i % len(vals)]                          # every value is shared by 4+ candidates, across strides
+        bbox[a] = 1.5
+        kps[a] = rng.uniform(-1, 1, 10)
+    a0 = cand[0]
+    scores[a0 + 1] = scores[a0]                                  # the other anchor of the same cell: same centre, same box -> IoU 1
+    bbox[a0 + 1] = 1.5
+    cand.append(a0 + 1)
+    outs, o = [], 0
+    for n in ns:
+        outs.append(scores[o:o + n].reshape(n, 1)); o += n
+    o = 0
+    for n in ns:
+        outs.append(bbox[o:o + n]); o += n
+    o = 0
+    for n in ns:
+        outs.append(kps[o:o + n]); o += n
+    return outs, np.array(sorted(cand))
+
+
+def test_tie_order_rule_of_the_oracle():
+    """ONE tie rule, pinned: the reference sorts twice with numpy's default argsort (scrfd.py:144 in detect,
+    :188 inside nms), which is unstable -- the oracle makes both sorts stable, and a stable ascending sort reversed, twice, leaves
+    equal scores in ASCENDING flat-anchor order when NMS walks them.  So detect() returns (score descending, anchor ascending) and of two
+    overlapping candidates with equal scores the LOWER anchor survives; SCRFD.nms() alone (one reversal) walks ties in DESCENDING
+    index order; max_num's argsort (one reversal) prefers the LATER of two equal areas."""
+    outs, cand = tied_heads()
+    det, kps = pp.detect_from_heads(outs, (640, 640))
+    flat_scores = np.concatenate([o.ravel() for o in outs[:3]])
+    want = sorted((int(a) for a in cand), key=lambda a: (-float(flat_scores[a]), a))
+    dropped = int(cand[np.flatnonzero(np.diff(cand) == 1)[0] + 1])      # the second anchor of the doubled cell loses to the first
+    want.remove(dropped)
+    assert len(det) == len(want)
+    assert np.array_equal(det[:, 4], flat_scores[want])
+    # identify every returned row by its decoded box centre -> anchor
+    ns = [12800, 3200, 800]
+    centres = []
+    for a in want:
+        lv = 0 if a < 12800 else (1 if a < 16000 else 2)
+        s = (8, 16, 32)[lv]
+        pix = (a - (0, 12800, 16000)[lv]) // 2
+        centres.append(((pix % (640 // s)) * s, (pix // (640 // s)) * s))
+    got = [((r[0] + r[2]) / 2, (r[1] + r[3]) / 2) for r in det]
+    assert np.allclose(got, centres)
+    # nms() alone: ties in descending index order
+    d = np.array([[0, 0, 10, 10, .9], [100, 0, 110, 10, .9], [200, 0, 210, 10, .9], [0, 0, 10, 10, .5]], dtype=np.float32)
+    assert [int(k) for k in pp.nms(d, 0.4)] == [2, 1, 0]
+    # max_num with equal areas: the later one first
+    det2, _ = pp.detect_from_heads(outs, (640, 640), max_num=3)
+    area = (det[:, 2] - det[:, 0]) * (det[:, 3] - det[:, 1])
+    pick = sorted(range(len(det)), key=lambda i: (-float(area[i]), -i))[:3]
+    assert len(set(np.round(area[pick], 3))) < 3                      # (the selection did have to break a tie)
+    assert np.array_equal(det2, det[pick])
