@@ -104,4 +104,8 @@ int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,
                       const float *b1, const void *w2, const float *b2, void *out, int C2p);
 
+// stem_rows.hip: the same fused stem on row-structured tiles (6 x PY pooled pixels, weights in registers, pooling in registers); the default
+int stem_rows_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,
+                     const float *b1, const void *w2, const float *b2, void *out, int C2p);
+
 }  // namespace fid

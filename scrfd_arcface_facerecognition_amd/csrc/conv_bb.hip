@@ -14,10 +14,12 @@
 //           rows 7rg..7rg+6 of the output tile).  BOTH filter banks of a wave's 16 couts (2 convs x 2 chunks x 9 taps x 4 VGPRs = 144
 //           registers) stay in registers for the kernel's lifetime (repack.hip kind 2 layout, packed by lower.py).
 //   LDS   = two x-patch buffers (this item / the next one, fetched by LDS-DMA a whole item ahead) + the intermediate tile in patch
-//           layout (16x16 pixels x 2 chunks of 32 channels, outside-the-image pixels written as 0: they are conv2's zero padding) whose
-//           space doubles as the staging area of the finished tile (16-byte row stores, whole pixel rows).
+//           layout (16x16 pixels x 2 chunks of 32 channels, outside-the-image pixels written as 0: they are conv2's zero padding) + the
+//           staging area of the finished tile (16-byte row stores, whole pixel rows).
 //   order = A: conv1 (2 chunks x 3 tap columns, row-sharing tap order of conv_chunked.hip) -> bias + ReLU -> LDS;  B: conv2 from LDS ->
-//           + bias + residual (read from the x patch) -> activation -> staging -> stores.  Four workgroup barriers per item.
+//           + bias + residual (read from the x patch) -> activation -> staging.  The staged tile's stores are issued at the start of the
+//           NEXT item and the next patch's LDS-DMA pieces one per tap column of conv1, so neither sits between two matrix phases with
+//           every pipe idle (measured with all of it at the item boundaries: 46 + 56 us of a 272 us block exposed).  Two barriers per item.
 #include "conv.h"
 
 namespace fid {
@@ -42,8 +44,8 @@ constexpr int MID_CH = MW * MW * 64, MID_BYTES = 2 * MID_CH;     // 32 KB
 constexpr int ROWB = 128, CPX = 8;                               // bytes / 16-byte chunks of a staged output pixel (64 couts)
 constexpr int ST_SLOTS = TO * 16 * CPX;                          // 16-byte slots of a staged tile (14 rows x 16 pixel columns)
 constexpr int ST_I = (ST_SLOTS + NWT * 64 - 1) / (NWT * 64);     // 4 stores per thread and item
-constexpr int OFF_X = 0, OFF_SPARE = 2 * X_ITEM, OFF_MID = OFF_SPARE + 1024, LDS_BYTES = OFF_MID + MID_BYTES + 512;
-static_assert(TO * 16 * ROWB <= MID_BYTES, "the staged tile lives in the intermediate tile's space");
+constexpr int STG_BYTES = TO * 16 * ROWB;                        // staged output tile (its 16-byte row stores are issued during the NEXT item)
+constexpr int OFF_X = 0, OFF_SPARE = 2 * X_ITEM, OFF_MID = OFF_SPARE + 1024, OFF_STG = OFF_MID + MID_BYTES + 512, LDS_BYTES = OFF_STG + STG_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ int swz64(int lin) { return (lin >> 1) & 3; }
@@ -93,25 +95,24 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
         if (row >= NPIX || j >= N_PIECES) py = 255;
         p_pk[k] = py | (px << 8) | (((((lane & 3) ^ swz64(row)) * 8) + ch * 32) << 16);
     }
-    auto issue_x = [&](int item, bool live, int buf) {          // exactly MAX_P instructions
-        int n, ty, tx;
-        decode_tile(live ? item : 0, n, ty, tx);
+    // piece k of the patch of tile (n, ty, tx) into buffer `buf` (live = false: a piece of zeros: the operation count per item stays exact)
+    auto issue_piece = [&](int k, int n, int ty, int tx, bool live, int buf) {
         const int y0 = ty * TO - 2, x0 = tx * TO - 2;
-        char *dst = smem + OFF_X + buf * X_ITEM;
-#pragma unroll
-        for (int k = 0; k < MAX_P; k++) {
-            const int j = wave + NWT * k;
-            int pk = p_pk[k];
-            asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
-            const int py = pk & 255, iy = y0 + py, ix = x0 + ((pk >> 8) & 255);
-            const bool in = live && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 8);
-            const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * 64 + (pk >> 16)) * 2) : OOB;
-            char *d = j < N_PIECES ? dst + j * 1024 : smem + OFF_SPARE;   // surplus piece: zeros into the spare KB
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)d, 16, vo, 0, 0, 0);
-        }
+        const int j = wave + NWT * k;
+        int pk = p_pk[k];
+        asm volatile("" : "+v"(pk));                            // opaque: unpack at the use
+        const int py = pk & 255, iy = y0 + py, ix = x0 + ((pk >> 8) & 255);
+        const bool in = live && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 8);
+        const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * 64 + (pk >> 16)) * 2) : OOB;
+        char *d = j < N_PIECES ? smem + OFF_X + buf * X_ITEM + j * 1024 : smem + OFF_SPARE;   // surplus piece: zeros into the spare KB
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)d, 16, vo, 0, 0, 0);
     };
-
-    issue_x(bid, true, 0);
+    {
+        int n, ty, tx;
+        decode_tile(bid, n, ty, tx);
+#pragma unroll
+        for (int k = 0; k < MAX_P; k++) issue_piece(k, n, ty, tx, true, 0);
+    }
 
     // ---- both filter banks of my 16 couts: kind 2 = [chunk][cout fragment 0..7][dx][dy][lane] x 16 B
     half8 w1[18], w2[18];                                       // [chunk * 9 + dy * 3 + dx]
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
     f32x4 acc[8];
     constexpr int PD = 2;
     // one 32-channel chunk of one conv: ROWS output rows of this wave from ROWS + 2 fragment rows x 3 tap columns
-    auto conv_chunk = [&](int base_off, auto rows_tag, auto pw_tag, const half8 *wv) {
+    auto conv_chunk = [&](int base_off, auto rows_tag, auto pw_tag, const half8 *wv, auto &&col_hook) {
         constexpr int ROWS = decltype(rows_tag)::value, PWV = decltype(pw_tag)::value, PH = ROWS + 2;
         int pb[2][4];
 #pragma unroll
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
             }
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) {
+            col_hook(dx);
             half8 pq[PD + 1];
             auto load_p = [&](int r, int set) {
                 const int K = r * PWV + dx;
@@ -179,24 +181,53 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
     };
     using std::integral_constant;
 
-    int item = bid;
+    // write-out of the tile staged by the item before (tile coordinates pn, pty, ptx; pn < 0: none -- the stores still issue, out of range,
+    // so that every item has exactly ST_I of them): 16-byte slot g = i * 512 + thread = (pixel g / 8, chunk g % 8); 64 pixels = 4 tile rows per round
+    auto write_out = [&](int pn, int pty, int ptx) {
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int q0 = t2 >> 3, c = t2 & 7;
+        const int pr0 = q0 >> 4, pc = q0 & 15;
+        const int oy0 = pty * TO, ox = ptx * TO + pc;
+        const bool okc = pn >= 0 && pc < TO && ox < a.W && !(a.ablate & 4);
+        const char *lsrc = smem + OFF_STG + q0 * ROWB + (((c + pc) % CPX) << 4);
+        const unsigned g0 = (unsigned)((((pn * a.H + oy0 + pr0) * a.W + ox) * 64 + c * 8) * 2);
+        const unsigned rstride = (unsigned)(a.W * 64 * 2);
+#pragma unroll
+        for (int i = 0; i < ST_I; i++) {
+            const int row = 4 * i + pr0;
+            const bool ok = okc && row < TO && oy0 + row < a.H;
+            const u32x4 v = *(const u32x4 *)(lsrc + (row < TO ? i * (64 * ROWB) : 0));
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, ok ? g0 + (unsigned)(4 * i) * rstride : OOB, 0, 0);
+        }
+    };
+    auto no_hook = [](int) {};
+
+    int item = bid, pn = -1, pty = 0, ptx = 0;
     for (int it = 0; it < my_items; it++, item += gridDim.x) {
         const int buf = it & 1;
-        // my pieces of this item's patch were requested a whole item ago; younger than them: the ST_I stores of the item before
-        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_I) : "memory");
-        raw_barrier();                                          // everybody's pieces; and everyone is done with the staged tile / the other patch buffer
-        issue_x(item + gridDim.x, it + 1 < my_items, buf ^ 1);
-        int n, ty, tx;
+        // operation order per wave and item: [top: ST_I stores of the tile staged by the item before] [conv1's six tap columns: one piece each
+        // of the NEXT item's patch].  So my pieces of this item's patch are the youngest operations in flight, requested most of an item ago.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();                                          // everybody's pieces; the tile of the item before is staged; its patch buffer is free
+        write_out(pn, pty, ptx);
+        int n, ty, tx, nn, nty, ntx;
         decode_tile(item, n, ty, tx);
+        const bool nlive = it + 1 < my_items;
+        decode_tile(nlive ? item + gridDim.x : 0, nn, nty, ntx);
+        auto fetch_hook0 = [&](int dx) { issue_piece(dx, nn, nty, ntx, nlive, buf ^ 1); };
+        auto fetch_hook1 = [&](int dx) { issue_piece(3 + dx, nn, nty, ntx, nlive, buf ^ 1); };
 
         // ================= A: conv1 on the 16x16 region (rows 8 rg .. 8 rg + 7 here) =================
 #pragma unroll
         for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(a.ablate & 1)) {
             const int xo = OFF_X + buf * X_ITEM + rg * (8 * PW * 64);
-            conv_chunk(xo, integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1);
-            conv_chunk(xo + P_BYTES, integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1 + 9);
+            conv_chunk(xo, integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1, fetch_hook0);
+            conv_chunk(xo + P_BYTES, integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1 + 9, fetch_hook1);
+        } else {
+#pragma unroll
+            for (int k = 0; k < MAX_P; k++) issue_piece(k, nn, nty, ntx, nlive, buf ^ 1);
         }
         {
             // intermediate pixel (row 8 rg + i, column frow) = image pixel (ty*14 - 1 + row, tx*14 - 1 + frow); outside the image it is
@@ -215,17 +246,16 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        raw_barrier();                                          // the intermediate tile is complete
+        raw_barrier();                                          // the intermediate tile is complete (and everyone has read the staged tile of the item before)
 
         // ================= B: conv2 on the 14x14 tile (rows 7 rg .. 7 rg + 6 here) =================
 #pragma unroll
         for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(a.ablate & 2)) {
             const int mo = OFF_MID + rg * (7 * MW * 64);
-            conv_chunk(mo, integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2);
-            conv_chunk(mo + MID_CH, integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2 + 9);
+            conv_chunk(mo, integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2, no_hook);
+            conv_chunk(mo + MID_CH, integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2 + 9, no_hook);
         }
-        raw_barrier();                                          // everyone has read the intermediate tile: its space becomes the staging area
         {
             int lo = lane;
             asm volatile("" : "+v"(lo));
@@ -233,7 +263,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
             // residual = x at the output pixel = patch pixel (row + 2, column + 2) of the chunk my couts live in
             const int g0 = (cw & 1) * 2 + (q4 >> 1);
             const char *xp = smem + OFF_X + buf * X_ITEM + (cw >> 1) * P_BYTES + (q4 & 1) * 8;
-            char *sp = smem + OFF_MID + fr * ROWB + (((cw * 2 + (q4 >> 1) + fr) % CPX) << 4) + (q4 & 1) * 8;   // chunk rotated by the pixel column
+            char *sp = smem + OFF_STG + fr * ROWB + (((cw * 2 + (q4 >> 1) + fr) % CPX) << 4) + (q4 & 1) * 8;   // chunk rotated by the pixel column
 #pragma unroll
             for (int i = 0; i < 7; i++) {
                 const int r = rg * 7 + i, lin = (r + 2) * PW + fr + 2;
@@ -245,27 +275,10 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        raw_barrier();                                          // the tile is staged
-        {
-            // write-out: 16-byte slot g = i * 512 + thread = (pixel g / 8, chunk g % 8); 512 / 8 = 64 pixels = 4 tile rows per round
-            int t2 = tid;
-            asm volatile("" : "+v"(t2));
-            const int q0 = t2 >> 3, c = t2 & 7;
-            const int pr0 = q0 >> 4, pc = q0 & 15;
-            const int oy0 = ty * TO, ox = tx * TO + pc;
-            const bool okc = pc < TO && ox < a.W && !(a.ablate & 4);
-            const char *lsrc = smem + OFF_MID + q0 * ROWB + (((c + pc) % CPX) << 4);
-            const unsigned g0 = (unsigned)((((n * a.H + oy0 + pr0) * a.W + ox) * 64 + c * 8) * 2);
-            const unsigned rstride = (unsigned)(a.W * 64 * 2);
-#pragma unroll
-            for (int i = 0; i < ST_I; i++) {
-                const int row = 4 * i + pr0;
-                const bool ok = okc && row < TO && oy0 + row < a.H;
-                const u32x4 v = *(const u32x4 *)(lsrc + (row < TO ? i * (64 * ROWB) : 0));
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, ok ? g0 + (unsigned)(4 * i) * rstride : OOB, 0, 0);
-            }
-        }
+        pn = n; pty = ty; ptx = tx;
     }
+    raw_barrier();                                              // the last tile is staged
+    write_out(pn, pty, ptx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the surplus pieces target this workgroup's LDS: drain before exit
 }
 

@@ -77,4 +77,5 @@ def test_arcface_from_onnx_file(ctx, tmp_path, basename, arch, fold_bn):
     assert 1 - float(emb @ ref / np.linalg.norm(emb) / np.linalg.norm(ref)) < 1e-3
     assert np.abs(emb / np.linalg.norm(emb) - ref / np.linalg.norm(ref)).max() < 1e-3
     feats = r.get_feat([crop, crop[:, ::-1].copy()])
-    assert feats.shape == (2, 512) and np.allclose(feats[0], emb, atol=1e-6)
+    # (another batch size picks other kernels / fp32 summation orders: equal to fp16 noise, not bit for bit)
+    assert feats.shape == (2, 512) and 1 - float(feats[0] @ emb / np.linalg.norm(feats[0]) / np.linalg.norm(emb)) < 1e-4

@@ -28,9 +28,12 @@ def stem_net(hw, c0, c2):
     return net
 
 
+# kernels: the row-structured stem (csrc/stem_rows.hip, the default) with 8 / 6 pooled rows per tile, and the first design on flattened
+# fragments (csrc/stem_fused.hip, FID_STEM_OLD=1)
+@pytest.mark.parametrize("kernel", ["rows8", "rows6", "flat"])
 @pytest.mark.parametrize("hw,c0,c2,batch", [((64, 64), 28, 56, 3), ((96, 160), 28, 56, 2), ((72, 100), 12, 24, 2),
-                                             ((320, 320), 28, 56, 1)])
-def test_fused_stem_matches_oracle_and_unfused(ctx, monkeypatch, hw, c0, c2, batch):
+                                             ((320, 320), 28, 56, 1), ((100, 76), 24, 24, 3), ((640, 640), 28, 56, 1)])
+def test_fused_stem_matches_oracle_and_unfused(ctx, monkeypatch, kernel, hw, c0, c2, batch):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     from scrfd_arcface_facerecognition_amd.lower import lower
     net = stem_net(hw, c0, c2)
@@ -38,6 +41,10 @@ def test_fused_stem_matches_oracle_and_unfused(ctx, monkeypatch, hw, c0, c2, bat
     images = np.random.default_rng(5).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
     images[0, :5, :7] = 0                      # real zero pixels are NOT padding (they map to -255/256)
     assert lower(net, P).op_names == ["stem.fused"]
+    if kernel == "flat":
+        monkeypatch.setenv("FID_STEM_OLD", "1")
+    else:
+        monkeypatch.setenv("FID_STEM_PY", kernel[4:])
     cn = CompiledNet(ctx, net, P, max_batch=batch)
     cn.run(images)
     fused = cn.read("stem.pool", batch)

@@ -57,13 +57,14 @@ def main():
         rows.append((gui, k, na[k], mf / (4 * busy_cu) if busy_cu else 0, mf / (4 * 256 * gui / 8) if gui else 0,
                      c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc, c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
                      d.get("SQ_WAIT_INST_LDS", 0) / wc, d.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, d.get("SQ_LDS_IDX_ACTIVE", 0)),
-                     c.get("SQ_INSTS_MFMA", 0), (gui / 8 / dur[k]) if dur.get(k) else 0.0, dur.get(k, 0.0) / max(1, na[k]) / 1e3))
+                     c.get("SQ_INSTS_MFMA", 0), (gui / 8 / dur[k]) if dur.get(k) else 0.0, dur.get(k, 0.0) / max(1, na[k]) / 1e3,
+                     d.get("SQ_ACTIVE_INST_VALU", 0) / wc, d.get("SQ_ACTIVE_INST_LDS", 0) / wc, d.get("SQ_ACTIVE_INST_SCA", 0) / wc))
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
     print("clk_ghz = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration (kernel trace of the same pass): the shader clock the chip held while the kernel ran")
-    print(f"{'kernel':56s} {'launches':>8s} {'time%':>6s} {'avg_us':>8s} {'clk_ghz':>7s} {'mfma_util':>9s} {'mfma_chip':>9s} {'wait':>6s} {'istall':>6s} {'active':>6s} {'lds_st':>6s} {'bankcf':>6s} {'mfma_insts':>12s}")
-    for gui, k, n, mu, mc, w, ws, ac, wl, bc, ni, clk, avg in rows[:40]:
-        print(f"{k[:56]:56s} {n:8d} {100 * gui / tot:6.1f} {avg:8.1f} {clk:7.2f} {100 * mu:9.1f} {100 * mc:9.1f} {100 * w:6.1f} {100 * ws:6.1f} {100 * ac:6.1f} {100 * wl:6.1f} {100 * bc:6.1f} {ni:12.0f}")
+    print(f"{'kernel':56s} {'launches':>8s} {'time%':>6s} {'avg_us':>8s} {'clk_ghz':>7s} {'mfma_util':>9s} {'mfma_chip':>9s} {'wait':>6s} {'istall':>6s} {'active':>6s} {'lds_st':>6s} {'bankcf':>6s} {'mfma_insts':>12s} {'valu':>6s} {'lds':>6s} {'salu':>6s}   (valu / lds / salu = SQ_ACTIVE_INST_* of the second pass over SQ_WAVE_CYCLES of the first)")
+    for gui, k, n, mu, mc, w, ws, ac, wl, bc, ni, clk, avg, va, la, sa in rows[:40]:
+        print(f"{k[:56]:56s} {n:8d} {100 * gui / tot:6.1f} {avg:8.1f} {clk:7.2f} {100 * mu:9.1f} {100 * mc:9.1f} {100 * w:6.1f} {100 * ws:6.1f} {100 * ac:6.1f} {100 * wl:6.1f} {100 * bc:6.1f} {ni:12.0f} {100 * va:6.1f} {100 * la:6.1f} {100 * sa:6.1f}")
 
 
 if __name__ == "__main__":
