@@ -86,6 +86,10 @@ bool conv_wr_applicable(const ConvArgs &a);
 bool conv_wr_resident_ok(const ConvArgs &a);
 int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident, int ring);
 
+// conv_ks.hip (generation 9, ns = 6): conv3x3_wr's one-tile x 64-cout item with the K axis split over two wave groups (few tiles: one item per CU); needs w_alt (kind 2)
+bool conv_ks_applicable(const ConvArgs &a);
+int conv_ks_launch(fid_ctx *ctx, const ConvArgs &a);
+
 // conv_s2.hip (generation 10): 3x3 / stride 2 with parity-plane patches and resident weights (64 / 96 input channels); needs w_alt (kind 2)
 bool conv_s2_applicable(const ConvArgs &a);
 int conv_s2_launch(fid_ctx *ctx, const ConvArgs &a);

@@ -835,6 +835,7 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
         d.bm = 256; d.bn = 64; out.push_back(d);       // one tile x 64 couts (few tiles: more items)
         d.ns = 4; out.push_back(d); d.ns = 0;          // ... with the patches three steps ahead (small batches: one workgroup per CU)
         if (conv_wr_resident_ok(a)) { d.bm = 256; d.bn = a.Cout_p; d.ns = 1; out.push_back(d); }   // the layer's weights resident in registers
+        if (conv_ks_applicable(a)) { d.bm = 256; d.bn = 64; d.ns = 6; out.push_back(d); }           // one tile x 64 couts, the K axis split over two wave groups (conv_ks.hip)
     }
     if (conv_pc_applicable(a)) {
         ConvPlan d{};
@@ -915,6 +916,7 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 8) return conv_pc2_launch(ctx, a);
     if (plan.gen == 10) return conv_s2_launch(ctx, a);
     if (plan.gen == 11) return conv_gw_launch(ctx, a, plan.bm, plan.bn);
+    if (plan.gen == 9 && plan.ns == 6) return conv_ks_launch(ctx, a);
     if (plan.gen == 9) return conv_wr_launch(ctx, a, plan.bm / 256, plan.bn, plan.ns == 1, plan.ns == 4 ? 4 : 2);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);

@@ -28,11 +28,11 @@ def forced_ran(cn, code):
         if code == 59:
             return p["gen"] == 5
         if code in (91, 92):
-            return p["gen"] == 9 and p["ns"] not in (1, 4) and p["bm"] // 256 == code % 10
+            return p["gen"] == 9 and p["ns"] not in (1, 4, 6) and p["bm"] // 256 == code % 10
         if code == 93:
             return p["gen"] == 9 and p["ns"] == 1
-        if code == 94:
-            return p["gen"] == 9 and p["ns"] == 4
+        if code in (94, 96):
+            return p["gen"] == 9 and p["ns"] == code % 10
         return p["gen"] == code
     return [p["name"] for p in cn.plans() if hit(p)]
 
@@ -53,7 +53,8 @@ def stack(hw, chans, res=True):
 # 59 = generation 5 with register-staged producers (FID_PC_RS); 8 = two tiles per weight chunk (the (14, 14) x 5 case: an odd tile count);
 # 91 / 92 = generation 9 (weights in registers; 14-row tiles on the 28 / 14-pixel maps, 10-row tiles on the 20-pixel maps, 16-row tiles elsewhere) with one tile x 64 couts /
 # a pair of tiles x 128 couts per item / (93) one tile x all couts with the layer's weights resident in registers (64 / 96 / 128-cout layers of 64 / 96 channels) / (94) one tile x 64 couts with a four-slot patch ring (pieces three steps ahead); 11 = implicit GEMM with the weights in registers (conv_gw: every conv with >= 96 couts, any kernel size / stride)
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 91, 92, 93, 94, 11, 25, 51, 59])
+# 96 = generation 9 with the K axis split over two wave groups (conv_ks.hip: one tile x 64 couts per item, 8 waves; layers with an even number of 32-channel chunks)
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 91, 92, 93, 94, 96, 11, 25, 51, 59])
 @pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2), ((37, 21), (64, 64), 3),
                                             ((14, 14), (128, 128), 5), ((20, 20), (64, 96), 4), ((20, 20), (224, 224), 3)])
 def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
@@ -61,7 +62,7 @@ def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     if gen == 59:
         monkeypatch.setenv("FID_FORCE_GEN", "5")
         monkeypatch.setenv("FID_PC_RS", "1")
-    elif gen in (25, 51, 91, 92, 93, 94):
+    elif gen in (25, 51, 91, 92, 93, 94, 96):
         monkeypatch.setenv("FID_FORCE_GEN", str(gen // 10))
         monkeypatch.setenv("FID_FORCE_NS", str(gen % 10))
     else:
