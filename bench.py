@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec); ~6.3 TB/s is what a streaming copy achieves
-PROFILE_DIRS = ("r02", "r01")
+PROFILE_DIRS = ("r03", "r02", "r01")
 # persisted kernel plan (per conv op and batch size: kernel family / tile / split-K), keyed by device name and layer-table hash: with it
 # every box runs the same kernels and fp32 summation orders (bit-identical heads / embeddings) and nothing is timed at start-up.
 # The tracked file is loaded READ-ONLY (FID_PLAN_RO): picks missing from it are tuned as before but never written back by a bench
@@ -104,6 +104,8 @@ def op_bytes(cn, oi, n):
         t = tens[tid]
         return int(t[T_H]) * int(t[T_W]) * int(t[T_CP]) * (4 if int(t[T_DTYPE]) == 1 else 2)
     b = tb(int(op[W_DST])) * n + max(0, int(op[W_WBYTES]))
+    if int(op[0]) == 6:                                    # fused residual block (csrc/conv_bb.hip): two 64x9x64 fp16 filter banks; its intermediate map is never stored
+        b += 2 * 64 * 9 * 64 * 2
     b += tb(int(op[W_SRC])) * n if int(op[W_SRC]) >= 0 else cn.in_hw[0] * cn.in_hw[1] * 3 * n
     if int(op[W_RES]) >= 0:
         b += tb(int(op[W_RES])) * n
@@ -114,7 +116,7 @@ def op_bytes(cn, oi, n):
 
 def mfma_roofline(pipe, frames_dev, batch, F):
     """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs and bytes."""
-    from scrfd_arcface_facerecognition_amd.lower import OP_CONV, OP_STEM, OP_STEMFUSED
+    from scrfd_arcface_facerecognition_amd.lower import OP_BBLOCK, OP_CONV, OP_DWPW, OP_STEM, OP_STEMFUSED
     tot_ms, tot_flop, tot_bytes, launches, per_net = 0.0, 0.0, 0.0, 0, {}
     for name, cn, imgs, n in (("scrfd_10g", pipe.det, frames_dev, batch), ("arcface_r50", pipe.rec, pipe.crops, batch * F)):
         best = None
@@ -124,7 +126,7 @@ def mfma_roofline(pipe, frames_dev, batch, F):
         t, fl, by, k = 0.0, 0.0, 0.0, 0
         by_name = {nd.name: nd for nd in cn.net.nodes}
         for oi, names in enumerate(cn.low.op_nodes):
-            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED):
+            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED, OP_BBLOCK, OP_DWPW):
                 continue
             macs = sum(node_macs(cn.net, by_name[nm]) for nm in names)
             t += float(best[oi]); fl += 2.0 * macs * n; by += op_bytes(cn, oi, n); k += 1

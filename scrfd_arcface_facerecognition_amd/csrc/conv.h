@@ -101,8 +101,13 @@ int conv_gw_launch(fid_ctx *ctx, const ConvArgs &a, int bm, int bn);
 
 // conv_bb.hip: a residual BasicBlock on 64 channels (conv3x3 + ReLU, conv3x3, + input, activation) in one launch; w1 / w2 are repack
 // kind 2 images packed by lower.py
-int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1, const void *w2, const float *b2, void *out, int B, int H, int W,
-                   int act2, int rev);
+int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1, int ncls1, int act1, const float *s1, const void *w2, const float *b2,
+                   void *out, int B, int H, int W, int act2, int rev);
+
+// dwpw.hip: depthwise 3x3 (stride 1 | 2, pad 1) + the pointwise 1x1 conv that consumes it, one launch (MobileFaceNet bottlenecks, SCRFD-500M)
+bool dwpw_applicable(int Gp, int Cout_p);
+int dwpw_launch(fid_ctx *ctx, const void *in, const float *dw_w, const float *dw_b, const float *dw_s, int dw_act, const void *pw_w, const float *pw_b,
+                const float *pw_s, int pw_act, const void *res, void *out, int B, int H, int W, int Ho, int Wo, int Gp, int Cout_p, int stride);
 
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,

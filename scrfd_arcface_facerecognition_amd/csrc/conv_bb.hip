@@ -45,7 +45,8 @@ constexpr int ROWB = 128, CPX = 8;                               // bytes / 16-b
 constexpr int ST_SLOTS = TO * 16 * CPX;                          // 16-byte slots of a staged tile (14 rows x 16 pixel columns)
 constexpr int ST_I = (ST_SLOTS + NWT * 64 - 1) / (NWT * 64);     // 4 stores per thread and item
 constexpr int STG_BYTES = TO * 16 * ROWB;                        // staged output tile (its 16-byte row stores are issued during the NEXT item)
-constexpr int OFF_X = 0, OFF_SPARE = 2 * X_ITEM, OFF_MID = OFF_SPARE + 1024, OFF_STG = OFF_MID + MID_BYTES + 512, LDS_BYTES = OFF_STG + STG_BYTES;
+constexpr int TAB_BYTES = 9 * 64 * 4;                            // conv1's bias rows (IResNet form: 9 border classes)
+constexpr int OFF_X = 0, OFF_SPARE = 2 * X_ITEM, OFF_MID = OFF_SPARE + 1024, OFF_STG = OFF_MID + MID_BYTES + 512, OFF_TAB = OFF_STG + STG_BYTES, LDS_BYTES = OFF_TAB + TAB_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ int swz64(int lin) { return (lin >> 1) & 3; }
@@ -54,7 +55,9 @@ __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "me
 struct BBArgs {
     const void *in;
     const void *w1, *w2;      // repack kind 2 images of the two filter banks (64 couts padded to a block of 128)
-    const float *b1, *b2;     // fp32 [64]
+    const float *b1, *b2;     // fp32 [ncls1][64] / [64]
+    const float *s1;          // fp32 [64] PReLU slopes of conv1 (act1 == ACT_PRELU)
+    int act1, ncls1;          // conv1: ACT_RELU | ACT_PRELU; 1 bias row, or 9 border-class rows (a BatchNorm folded in front of the zero-padded conv)
     void *out;
     int H, W;
     int act2;                 // activation after the residual add (ACT_RELU | ACT_NONE)
@@ -65,6 +68,9 @@ struct BBArgs {
     int ablate;               // FID_BB_ABLATE timing experiments (wrong results): 1 no conv1, 2 no conv2, 4 no stores, 8 no patch fetch
 };
 
+// IR = false: SCRFD's block (plain bias + ReLU after conv1; the bias lives in registers).  IR = true: any conv1 epilogue -- bias rows by border
+// class from an LDS table, ReLU or PReLU (IResNet: BN - conv - BN - PReLU - conv - BN, + input).
+template <bool IR>
 __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,6 +135,12 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
                 }
     }
     const f32x4 bias1 = *(const f32x4 *)(a.b1 + cw * 16 + fq * 4), bias2 = *(const f32x4 *)(a.b2 + cw * 16 + fq * 4);
+    f32x4 slope1 = f32x4{0.f, 0.f, 0.f, 0.f};                   // (ReLU = PReLU with slope 0)
+    if constexpr (IR) {
+        if (a.act1 == ACT_PRELU) slope1 = *(const f32x4 *)(a.s1 + cw * 16 + fq * 4);
+        float *tb = (float *)(smem + OFF_TAB);
+        for (int i = tid; i < a.ncls1 * 64; i += NWT * 64) tb[i] = a.b1[i];
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 18; i++) asm volatile("" : "+v"(w1[i]), "+v"(w2[i]));
@@ -238,9 +250,19 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
             const int gx = tx * TO - 1 + fr, gy0 = ty * TO - 1 + rg * 8;
             const bool xin = (unsigned)gx < (unsigned)a.W;
             char *mp = smem + OFF_MID + (cw >> 1) * MID_CH + (rg * 8 * MW + fr) * 64 + ((((cw & 1) * 2 + (q4 >> 1)) ^ swz64(fr)) << 4) + (q4 & 1) * 8;
+            const int xc = a.ncls1 == 9 ? (gx == 0 ? 0 : (gx == a.W - 1 ? 2 : 1)) : 0;
+            const float *tb = (const float *)(smem + OFF_TAB) + xc * 64 + cw * 16 + q4 * 4;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                half4 h = __builtin_elementwise_max(__builtin_convertvector(acc[i] + bias1, half4), half4{0, 0, 0, 0});
+                half4 h;
+                if constexpr (IR) {
+                    const int gy = gy0 + i, yc = a.ncls1 == 9 ? (gy == 0 ? 0 : (gy == a.H - 1 ? 2 : 1)) : 0;
+                    f32x4 v = acc[i] + *(const f32x4 *)(tb + yc * 192);
+                    v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + slope1 * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                    h = __builtin_convertvector(v, half4);
+                } else {
+                    h = __builtin_elementwise_max(__builtin_convertvector(acc[i] + bias1, half4), half4{0, 0, 0, 0});
+                }
                 if (!(xin && (unsigned)(gy0 + i) < (unsigned)a.H)) h = half4{0, 0, 0, 0};
                 *(half4 *)(mp + i * (MW * 64)) = h;
             }
@@ -284,14 +306,15 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
 
 }  // namespace
 
-// x [B, H, W, 64] fp16 -> out [B, H, W, 64]; w1 / w2: repack kind 2 images (147 456 B each), b1 / b2 fp32 [64]
-int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1, const void *w2, const float *b2, void *out, int B, int H, int W,
-                   int act2, int rev) {
+// x [B, H, W, 64] fp16 -> out [B, H, W, 64]; w1 / w2: repack kind 2 images (147 456 B each), b1 fp32 [ncls1][64], b2 fp32 [64], s1 fp32 [64] or NULL
+int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1, int ncls1, int act1, const float *s1, const void *w2, const float *b2,
+                   void *out, int B, int H, int W, int act2, int rev) {
     FID_REQUIRE(in && w1 && w2 && b1 && b2 && out && B > 0 && H >= 3 && W >= 3, "conv_bb: bad arguments");
-    FID_REQUIRE(act2 == ACT_RELU || act2 == ACT_NONE, "conv_bb: activation %d", act2);
+    FID_REQUIRE((act2 == ACT_RELU || act2 == ACT_NONE) && (act1 == ACT_RELU || (act1 == ACT_PRELU && s1)) && (ncls1 == 1 || ncls1 == 9), "conv_bb: activations %d / %d, %d bias rows", act1, act2, ncls1);
     BBArgs a{};
     a.in = in; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2; a.out = out;
     a.H = H; a.W = W; a.act2 = act2; a.rev = rev;
+    a.s1 = s1; a.act1 = act1; a.ncls1 = ncls1;
     a.tiles_x = cdiv(W, TO);
     a.tiles_per_img = a.tiles_x * cdiv(H, TO);
     a.n_tiles = B * a.tiles_per_img;
@@ -301,9 +324,14 @@ int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1
     a.io_bytes = (unsigned)bytes;
     static const int ablate = getenv("FID_BB_ABLATE") ? atoi(getenv("FID_BB_ABLATE")) : 0;
     a.ablate = ablate;
-    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb, LDS_BYTES));
     const int grid = std::min(a.n_tiles, ctx->num_cus);
-    hipLaunchKernelGGL(conv_bb, dim3(grid), dim3(NWT * 64), LDS_BYTES, ctx->stream, a);
+    if (ncls1 == 9 || act1 == ACT_PRELU) {
+        FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb<true>, LDS_BYTES));
+        hipLaunchKernelGGL(conv_bb<true>, dim3(grid), dim3(NWT * 64), LDS_BYTES, ctx->stream, a);
+    } else {
+        FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb<false>, LDS_BYTES));
+        hipLaunchKernelGGL(conv_bb<false>, dim3(grid), dim3(NWT * 64), LDS_BYTES, ctx->stream, a);
+    }
     FID_HIP(hipGetLastError());
     return FID_OK;
 }

@@ -4,7 +4,7 @@
 
 namespace fid {
 
-enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6 };
+enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6, OP_DWPW = 7 };
 
 // int32 word indices inside one op record (FID_OP_WORDS = 32 words)
 enum : int {
@@ -32,7 +32,10 @@ enum : int {
     W_F_MACS_LO = 26, W_F_MACS_HI = 27,   // algorithmic MACs per image of the fused group (cost accounting)
     // OP_BBLOCK (conv_bb.hip; lower.py): blob offsets of the two convs' weights in repack kind 2 order and of their biases; W_ACT = the activation
     // after the residual add; W_F_MACS_* = MACs per image of both convs
-    W_B_W1 = 20, W_B_B1 = 21, W_B_W2 = 22, W_B_B2 = 23,
+    W_B_W1 = 20, W_B_B1 = 21, W_B_W2 = 22, W_B_B2 = 23, W_B_S1 = 24, W_B_ACT1 = 25,   // (+ conv1's PReLU slopes or -1, its activation; W_FLAGS & CF_BORDER: 9 bias rows)
+    // OP_DWPW (dwpw.hip; lower.py): the record is the POINTWISE conv's (weights, bias, slopes, activation, residual, W_DST) with W_SRC = the
+    // depthwise layer's input and W_STRIDE = its stride; the depthwise layer's fp32 tables and activation: W_F_MACS_* = MACs of both
+    W_D_WOFF = 20, W_D_BOFF = 21, W_D_SOFF = 22, W_D_ACT = 23,
     // OP_CONV fused with the block's shortcut (lower.py; conv_s2.hip DUAL): second output's tensor id + 1 (0: plain conv), its activation,
     // padded couts of the first output; W_F_MACS_LO then holds the shortcut's MACs per image
     W_X_DST2 = 20, W_X_ACT2 = 21, W_X_COUT1P = 22,

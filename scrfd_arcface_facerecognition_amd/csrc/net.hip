@@ -557,9 +557,24 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             const TensorView src = view(net, op[W_SRC], first);
             FID_REQUIRE(src.Cp == 64 && dst.Cp == 64 && src.H == dst.H && src.W == dst.W && src.dtype == 0 && dst.dtype == 0, "op %d: bad fused block record", oi);
             const int rev = net->alternate && !net->tdir[op[W_SRC]];
-            FID_TRY(conv_bb_launch(ctx, src.ptr, blob + op[W_B_W1], (const float *)(blob + op[W_B_B1]), blob + op[W_B_W2],
-                                   (const float *)(blob + op[W_B_B2]), dst.ptr, batch, dst.H, dst.W, op[W_ACT], rev));
+            FID_TRY(conv_bb_launch(ctx, src.ptr, blob + op[W_B_W1], (const float *)(blob + op[W_B_B1]), (op[W_FLAGS] & CF_BORDER) ? 9 : 1, op[W_B_ACT1],
+                                   op[W_B_S1] >= 0 ? (const float *)(blob + op[W_B_S1]) : nullptr, blob + op[W_B_W2], (const float *)(blob + op[W_B_B2]), dst.ptr,
+                                   batch, dst.H, dst.W, op[W_ACT], rev));
             net->tdir[op[W_DST]] = (char)rev;
+            break;
+        }
+        case OP_DWPW: {
+            const TensorView src = view(net, op[W_SRC], first);
+            const void *res = nullptr;
+            if (op[W_RES] >= 0) {
+                const TensorView r = view(net, op[W_RES], first);
+                FID_REQUIRE(r.H == dst.H && r.W == dst.W && r.Cp == dst.Cp && r.dtype == 0, "op %d: residual shape", oi);
+                res = r.ptr;
+            }
+            FID_REQUIRE(src.dtype == 0 && dst.dtype == 0 && op[W_D_WOFF] >= 0 && op[W_D_BOFF] >= 0 && op[W_WOFF] >= 0, "op %d: bad depthwise + pointwise record", oi);
+            FID_TRY(dwpw_launch(ctx, src.ptr, (const float *)(blob + op[W_D_WOFF]), (const float *)(blob + op[W_D_BOFF]),
+                                op[W_D_SOFF] >= 0 ? (const float *)(blob + op[W_D_SOFF]) : nullptr, op[W_D_ACT], blob + op[W_WOFF], bias, slope, op[W_ACT], res,
+                                dst.ptr, batch, src.H, src.W, dst.H, dst.W, src.Cp, dst.Cp, op[W_STRIDE]));
             break;
         }
         case OP_MAXPOOL: {
@@ -740,7 +755,7 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
             return FID_E_INVALID;
         }
         const int32_t *dt = &net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS];
-        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK)
+        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK || op[W_TYPE] == OP_DWPW)
             net->macs_per_image += (double)(((unsigned long long)(unsigned)op[W_F_MACS_HI] << 32) | (unsigned)op[W_F_MACS_LO]);
         if (op[W_TYPE] == OP_CONV && op[W_X_DST2] > 0) net->macs_per_image += (double)(unsigned)op[W_F_MACS_LO];   // the fused shortcut's share
         if (op[W_TYPE] == OP_CONV || op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_DWCONV)

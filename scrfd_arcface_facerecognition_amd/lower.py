@@ -10,6 +10,8 @@ models/scrfd.py:59-62, models/arcface.py:18-21), written down:
   * nearest-2x upsample + add (PAFPN top-down) and the residual add become epilogue flags;
   * a residual BasicBlock on 64 (padded) channels -- conv3x3+ReLU, conv3x3, + block input, activation -- becomes ONE op whose
     intermediate map never leaves the CU (csrc/conv_bb.hip; FID_NO_BB_FUSE=1 keeps the two convs);
+  * a depthwise 3x3 conv whose only consumer is a pointwise 1x1 conv (MobileFaceNet bottlenecks, SCRFD-500M) becomes ONE op with the
+    depthwise result in LDS (csrc/dwpw.hip) when FID_DWPW_FUSE=1 asks for it (measured slower than the two launches: off by default);
   * the three SCRFD output convs of a level become one conv with 2+8+20 output channels, sigmoid on
     the first two, bbox scale folded in, fp32 output;
   * blobFromImage's (x-127.5)*scale and BGR->RGB swap are folded into the first conv's weights;
@@ -28,7 +30,7 @@ import numpy as np
 from .archs import BN_EPS, Net, infer_shapes
 
 OP_WORDS, TENSOR_WORDS = 32, 8
-OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK = 1, 2, 3, 4, 5, 6
+OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK, OP_DWPW = 1, 2, 3, 4, 5, 6, 7
 ACT = {"none": 0, "relu": 1, "prelu": 2}
 CF_RES_UP2, CF_BORDER, CF_OUT_F32 = 1, 2, 4
 CPAD = 32
@@ -141,6 +143,43 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             W = W * a2[:, None, None, None]
             b = b * a2 + b2
         return W, b
+
+    def fold_conv(n, src_hw):
+        """full fold of a conv node: (W [cout, cin, k, k] f64, bias table [ncls, cout] f64, k, stride) with a BatchNorm in FRONT of a zero-padded
+        conv folded exactly (scale into the weights, shift into 9 border-class bias rows: a border pixel's missing taps contribute no shift), the
+        avg-pool of an "avg_down" shortcut as a 2x2 / stride-2 kernel and the trailing BatchNorm"""
+        W = P[n.wname + ".weight"].astype(np.float64)            # [cout, cin, k, k]
+        b = P[n.wname + ".bias"].astype(np.float64) if n.bias else np.zeros(n.cout)
+        k, stride, pad = n.k, n.stride, n.pad
+        if n.pre_avgpool:
+            assert k == 1 and pad == 0 and stride == 1
+            W = np.repeat(np.repeat(W, 2, axis=2), 2, axis=3) / 4.0
+            k, stride = 2, 2
+        bias_tab = None
+        if n.pre_bn:
+            a1, b1 = _bn_affine(P, n.wname + ".pre_bn")
+            shift = np.einsum("oikl,i->okl", W, b1)                # per-tap contribution of the BN shift
+            W = W * a1[None, :, None, None]
+            if pad == 0:
+                b = b + shift.sum(axis=(1, 2))
+            else:
+                assert k == 3 and pad == 1 and stride == 1 and src_hw[0] >= 2 and src_hw[1] >= 2, n.name
+                bias_tab = np.zeros((9, n.cout))
+                for yc in range(3):
+                    for xc in range(3):
+                        m = np.ones((3, 3))
+                        if yc == 0: m[0, :] = 0
+                        if yc == 2: m[2, :] = 0
+                        if xc == 0: m[:, 0] = 0
+                        if xc == 2: m[:, 2] = 0
+                        bias_tab[yc * 3 + xc] = b + (shift * m[None]).sum(axis=(1, 2))
+        if bias_tab is None:
+            bias_tab = b[None, :]
+        if n.post_bn:
+            a2, b2 = _bn_affine(P, n.wname + ".post_bn")
+            W = W * a2[:, None, None, None]
+            bias_tab = bias_tab * a2[None, :] + b2[None, :]
+        return W, bias_tab, k, stride
 
     # ---- SCRFD deep stem (conv/s2 - conv - conv - maxpool, all ReLU): one fused kernel (csrc/stem_fused.hip) ----
     import os
@@ -259,19 +298,26 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             skip.add(ni_ + 1)
         elif (n.kind == "conv" and n.groups == 1 and not os.environ.get("FID_NO_BB_FUSE") and nxt is not None and nxt.kind == "conv"
               and nxt.groups == 1 and n.k == 3 and nxt.k == 3 and n.stride == 1 and nxt.stride == 1 and n.pad == 1 and nxt.pad == 1
-              and n.act == "relu" and nxt.act in ("relu", "none") and n.res is None and nxt.res == n.src and nxt.src == n.name
-              and not n.res_up2 and not nxt.res_up2 and not n.pre_bn and not nxt.pre_bn and not n.pre_avgpool and not nxt.pre_avgpool
+              and n.act in ("relu", "prelu") and nxt.act in ("relu", "none") and n.res is None and nxt.res == n.src and nxt.src == n.name
+              and not n.res_up2 and not nxt.res_up2 and not nxt.pre_bn and not n.pre_avgpool and not nxt.pre_avgpool
               and n.src != "input" and tensors[tid[n.src]][1] == 64 and tensors[tid[n.src]][4] == 0 and _rup(n.cout, CPAD) == 64
-              and _rup(nxt.cout, CPAD) == 64 and n.name not in net.outputs
+              and _rup(nxt.cout, CPAD) == 64 and n.name not in net.outputs and tensors[tid[n.src]][2] >= 3 and tensors[tid[n.src]][3] >= 3
               and not any(getattr(x, "src", None) == n.name or getattr(x, "res", None) == n.name for x in net.nodes if x is not nxt)):
             # A residual BasicBlock on 64 stored channels (SCRFD-10G layer1): conv1 + ReLU -> conv2 -> + block input -> activation as ONE
             # launch (csrc/conv_bb.hip): conv1's output only feeds conv2, so it is never materialised.  Both filter banks go into the blob
             # in the register-fragment order the kernel loads (repack.hip kind 2).
+            # IResNet's form of the block (BN - conv - BN - PReLU - conv - BN, + input: arcface_r50 layer1.1 / 1.2) is covered too: the leading
+            # BatchNorm folds into conv1 with 9 border-class bias rows (flag CF_BORDER), PReLU slopes travel in word 24.
             m = nxt
-            W1, b1 = folded(n)
-            W2, b2 = folded(m)
-            offs = [blob.add(repack_kind2(pack_weights(W1, 64, 64)))[0], blob.add(padded(b1, 64))[0],
-                    blob.add(repack_kind2(pack_weights(W2, 64, 64)))[0], blob.add(padded(b2, 64))[0]]
+            src_t = tensors[tid[n.src]]
+            W1, bt1, _, _ = fold_conv(n, (src_t[2], src_t[3]))
+            W2, bt2, _, _ = fold_conv(m, (src_t[2], src_t[3]))
+            assert bt2.shape[0] == 1
+            b1t = np.zeros((bt1.shape[0], 64), dtype=np.float32)
+            b1t[:, :n.cout] = bt1
+            offs = [blob.add(repack_kind2(pack_weights(W1, 64, 64)))[0], blob.add(b1t)[0],
+                    blob.add(repack_kind2(pack_weights(W2, 64, 64)))[0], blob.add(padded(bt2[0], 64))[0]]
+            s1_off = blob.add(padded(P[n.wname + ".prelu"], 64))[0] if n.act == "prelu" else -1
             _, ho, wo = shp[m.name]
             dst = new_tensor(m.name, m.cout, ho, wo)
             rec = [0] * OP_WORDS
@@ -282,6 +328,8 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             rec[13] = rec[15] = rec[16] = -1
             rec[18] = 1
             rec[20:24] = offs
+            rec[24], rec[25] = s1_off, ACT[n.act]
+            rec[11] = CF_BORDER if bt1.shape[0] == 9 else 0
             macs = ho * wo * 9 * (n.cout * n.cin + m.cout * m.cin)
             rec[26], rec[27] = macs & 0xFFFFFFFF, macs >> 32
             if rec[26] >= 2 ** 31:
@@ -296,39 +344,9 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             _, ho, wo = shp[n.name]
             src_t = tensors[tid[n.src]]
             cin_p, cout_p = src_t[1], _rup(cout, CPAD)
-            W = P[n.wname + ".weight"].astype(np.float64)            # [cout, cin, k, k]
-            b = P[n.wname + ".bias"].astype(np.float64) if n.bias else np.zeros(cout)
-            k, stride, pad = n.k, n.stride, n.pad
-            if n.pre_avgpool:
-                assert k == 1 and pad == 0 and stride == 1
-                W = np.repeat(np.repeat(W, 2, axis=2), 2, axis=3) / 4.0
-                k, stride = 2, 2
-            ncls = 1
-            bias_tab = None
-            if n.pre_bn:
-                a1, b1 = _bn_affine(P, n.wname + ".pre_bn")
-                shift = np.einsum("oikl,i->okl", W, b1)                # per-tap contribution of the BN shift
-                W = W * a1[None, :, None, None]
-                if pad == 0:
-                    b = b + shift.sum(axis=(1, 2))
-                else:
-                    assert k == 3 and pad == 1 and stride == 1 and src_t[2] >= 2 and src_t[3] >= 2, n.name
-                    ncls = 9
-                    bias_tab = np.zeros((9, cout))
-                    for yc in range(3):
-                        for xc in range(3):
-                            m = np.ones((3, 3))
-                            if yc == 0: m[0, :] = 0
-                            if yc == 2: m[2, :] = 0
-                            if xc == 0: m[:, 0] = 0
-                            if xc == 2: m[:, 2] = 0
-                            bias_tab[yc * 3 + xc] = b + (shift * m[None]).sum(axis=(1, 2))
-            if bias_tab is None:
-                bias_tab = b[None, :]
-            if n.post_bn:
-                a2, b2 = _bn_affine(P, n.wname + ".post_bn")
-                W = W * a2[:, None, None, None]
-                bias_tab = bias_tab * a2[None, :] + b2[None, :]
+            W, bias_tab, k, stride = fold_conv(n, (src_t[2], src_t[3]))
+            pad = n.pad
+            ncls = bias_tab.shape[0]
             Wp = pack_weights(W, cin_p, cout_p)
             woff, wbytes = blob.add(Wp)
             bt = np.zeros((ncls, cout_p), dtype=np.float32)
@@ -356,6 +374,33 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             woff, wbytes = blob.add(Wd)
             boff, _ = blob.add(padded(b, cp))
             soff = blob.add(padded(P[n.wname + ".prelu"], cp))[0] if n.act == "prelu" else -1
+            m = nxt
+            # (opt-in, FID_DWPW_FUSE=1: measured SLOWER than the two launches -- MobileFaceNet at 32 faces 0.532 vs 0.502 ms, one face 0.350 vs
+            # 0.299 ms: these layers are a few hundred 2-us items, two wide launches hide their load latencies better than one deep one)
+            if (os.environ.get("FID_DWPW_FUSE") and m is not None and m.kind == "conv" and m.groups == 1 and m.k == 1 and m.pad == 0
+                    and m.stride == 1 and m.src == n.name and not m.pre_bn and not m.pre_avgpool and not m.res_up2 and n.k == 3 and n.pad == 1
+                    and n.stride in (1, 2) and cp in (32, 64, 128, 256, 512) and n.name not in net.outputs and m.res != n.name
+                    and not any(getattr(x, "src", None) == n.name or getattr(x, "res", None) == n.name for x in net.nodes if x is not m)):
+                # depthwise 3x3 + the pointwise 1x1 that consumes it: one op, the depthwise result stays in LDS (csrc/dwpw.hip).  The record is
+                # the pointwise conv's; words 20-23 hold the depthwise tables / activation, 26 / 27 the MACs of both layers.
+                Wm, bm = folded(m)
+                cout_p = _rup(m.cout, CPAD)
+                pw_off, pw_bytes = blob.add(pack_weights(Wm, cp, cout_p))
+                pb_off, _ = blob.add(padded(bm, cout_p)[None, :])
+                ps_off = blob.add(padded(P[m.wname + ".prelu"], cout_p))[0] if m.act == "prelu" else -1
+                _, mho, mwo = shp[m.name]
+                dst = new_tensor(m.name, m.cout, mho, mwo)
+                emit(m.name, type=OP_DWPW, src=tid[n.src], dst=dst, res=tid[m.res] if m.res else -1, kh=3, kw=3, stride=n.stride, pad=1, cin=c,
+                     cout=m.cout, act=ACT[m.act], flags=0, woff=pw_off, wbytes=pw_bytes, boff=pb_off, soff=ps_off, wrows=cout_p)
+                ops[-1][20], ops[-1][21], ops[-1][22], ops[-1][23] = woff, boff, soff, ACT[n.act]
+                macs = ho * wo * c * n.k * n.k + mho * mwo * m.cout * m.cin
+                ops[-1][26], ops[-1][27] = macs & 0xFFFFFFFF, macs >> 32
+                if ops[-1][26] >= 2 ** 31:
+                    ops[-1][26] -= 2 ** 32
+                op_nodes[-1] = [n.name, m.name]
+                out.fused_groups[m.name] = [n.name, m.name]
+                skip.add(ni_ + 1)
+                continue
             dst = new_tensor(n.name, c, ho, wo, Cp=cp)
             emit(n.name, type=OP_DWCONV, src=tid[n.src], dst=dst, kh=n.k, kw=n.k, stride=n.stride, pad=n.pad,
                  cin=c, cout=c, act=ACT[n.act], woff=woff, wbytes=wbytes, boff=boff, soff=soff, wrows=cp, groups=c)

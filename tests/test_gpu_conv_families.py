@@ -177,19 +177,22 @@ def test_fused_shortcut_stride2(ctx, monkeypatch, fuse, hw, planes, batch):
 # the residual from the input patch): fused and unfused lowering against the oracle -- maps that are / are not multiples of 14, maps smaller
 # than a tile, one image, two chained blocks (the second walks its items in the other direction), both activations after the add
 @pytest.mark.parametrize("fuse", [True, False])
+# ("ir": IResNet's form -- BN - conv - BN - PReLU - conv - BN, + input -- conv1 then carries 9 border-class bias rows and PReLU slopes)
 @pytest.mark.parametrize("hw,planes,batch,act2", [((56, 84), 56, 3, "relu"), ((37, 45), 64, 2, "relu"), ((12, 20), 56, 5, "none"), ((160, 160), 56, 1, "relu"),
-                                                  ((29, 16), 40, 4, "relu")])
+                                                  ((29, 16), 40, 4, "relu"), ((56, 56), 64, 3, "ir"), ((23, 31), 64, 2, "ir"), ((14, 14), 64, 5, "ir")])
 def test_fused_basic_block(ctx, monkeypatch, fuse, hw, planes, batch, act2):
     from scrfd_arcface_facerecognition_amd import lower
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     if not fuse:
         monkeypatch.setenv("FID_NO_BB_FUSE", "1")
     net = Net("t", hw, 127.5, 1.0 / 128.0)
-    net.add(Conv("s", "input", 3, planes, act="relu"))
-    net.add(Conv("b0.conv1", "s", planes, planes, act="relu"))
-    net.add(Conv("b0.conv2", "b0.conv1", planes, planes, act=act2, res="s"))
-    net.add(Conv("b1.conv1", "b0.conv2", planes, planes, act="relu"))
-    net.add(Conv("b1.conv2", "b1.conv1", planes, planes, act="relu", res="b0.conv2"))
+    ir = act2 == "ir"
+    a1 = dict(act="prelu", pre_bn=True) if ir else dict(act="relu")
+    net.add(Conv("s", "input", 3, planes, act="prelu" if ir else "relu"))
+    net.add(Conv("b0.conv1", "s", planes, planes, **a1))
+    net.add(Conv("b0.conv2", "b0.conv1", planes, planes, act="none" if ir else act2, res="s"))
+    net.add(Conv("b1.conv1", "b0.conv2", planes, planes, **a1))
+    net.add(Conv("b1.conv2", "b1.conv1", planes, planes, act="none" if ir else "relu", res="b0.conv2"))
     net.outputs = ["b1.conv2"]
     P = archs.synth_params(net, seed=23)
     low = lower.lower(net, P)
@@ -205,3 +208,44 @@ def test_fused_basic_block(ctx, monkeypatch, fuse, hw, planes, batch, act2):
         r = np.transpose(ref[nm], (0, 2, 3, 1))
         assert got[nm].shape == r.shape
         assert np.abs(got[nm] - r).max() / np.abs(r).max() < 8e-3, nm
+
+
+# depthwise 3x3 + the pointwise 1x1 that consumes it as ONE launch (lower.py pattern; csrc/dwpw.hip: the depthwise result stays in LDS): fused
+# and unfused lowering against the oracle -- MobileFaceNet's bottleneck shapes (stride 1 with a residual, stride 2 without), odd maps whose
+# pixel count is no multiple of the 64-pixel item, a single image, every activation pair
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("hw,groups,cout,stride,res,acts,batch", [((28, 28), 128, 128, 1, True, ("prelu", "none"), 3), ((28, 28), 256, 256, 2, False, ("prelu", "none"), 2),
+                                                                   ((14, 14), 512, 256, 2, False, ("prelu", "prelu"), 5), ((37, 21), 64, 96, 1, False, ("relu", "relu"), 1),
+                                                                   ((16, 24), 32, 48, 2, False, ("none", "relu"), 4)])
+def test_fused_depthwise_pointwise(ctx, monkeypatch, fuse, hw, groups, cout, stride, res, acts, batch):
+    from scrfd_arcface_facerecognition_amd import lower
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    if fuse:
+        monkeypatch.setenv("FID_DWPW_FUSE", "1")                 # (opt-in: measured slower than the two launches on MobileFaceNet)
+    else:
+        monkeypatch.delenv("FID_DWPW_FUSE", raising=False)
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 64, act="relu"))
+    net.add(Conv("p1", "s", 64, groups, k=1, pad=0, act="prelu"))
+    if res:
+        assert cout == groups
+        net.add(Conv("p0", "p1", groups, cout, k=1, pad=0))
+        src = "p0"
+        net.add(Conv("q1", src, cout, groups, k=1, pad=0, act="prelu"))
+        net.add(Conv("dw", "q1", groups, groups, stride=stride, groups=groups, act=acts[0]))
+        net.add(Conv("pw", "dw", groups, cout, k=1, pad=0, act=acts[1], res=src))
+    else:
+        net.add(Conv("dw", "p1", groups, groups, stride=stride, groups=groups, act=acts[0]))
+        net.add(Conv("pw", "dw", groups, cout, k=1, pad=0, act=acts[1]))
+    net.outputs = ["pw"]
+    P = archs.synth_params(net, seed=31)
+    low = lower.lower(net, P)
+    assert (sum(int(r[0]) == 7 for r in low.ops) == 1) == fuse and (sum(int(r[0]) == 4 for r in low.ops) == 0) == fuse
+    images = np.random.default_rng(10).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    cn.run(images)
+    got = cn.read("pw", batch)
+    cn.close()
+    ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["pw"], (0, 2, 3, 1))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3

@@ -122,7 +122,13 @@ def test_arcface_r50_embeddings(ctx):
     assert cosine(r[0], r[1]) < 0.999
 
 
-def test_arcface_mbf_embeddings(ctx):
+@pytest.mark.parametrize("dwpw", [False, True])
+def test_arcface_mbf_embeddings(ctx, monkeypatch, dwpw):
+    """dwpw: every depthwise layer fused with the pointwise conv behind it (csrc/dwpw.hip; opt-in, FID_DWPW_FUSE=1)"""
+    if dwpw:
+        monkeypatch.setenv("FID_DWPW_FUSE", "1")
+    else:
+        monkeypatch.delenv("FID_DWPW_FUSE", raising=False)
     net = archs.mobilefacenet()
     P = archs.synth_params(net, seed=0)
     images = np.random.default_rng(12).integers(0, 256, (2, 112, 112, 3), dtype=np.uint8)
