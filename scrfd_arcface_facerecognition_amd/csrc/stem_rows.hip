@@ -353,6 +353,315 @@ __global__ void __launch_bounds__(256, 2) scrfd_stem_rows(const StemRArgs a) {
     }
 }
 
+
+// ---- the same stem with the two halves of a tile's work on DIFFERENT waves, one tile apart ------------------------------------------------
+// In scrfd_stem_rows every wave walks all stages of its tile: 255 MFMAs (4 080 cycles) inside ~20 000 cycles of conversion, gather, epilogues,
+// pooling and barriers, and the second workgroup of the CU -- same program, same phase -- fills the pipe to ~40 %.  Here a workgroup has 8 waves
+// in two ROLES: waves 0-3 ("front") convert the input patch and run conv0 + conv1 of tile t + 1 while waves 4-7 ("back") run conv2 + the pool +
+// the write-out of tile t from the conv1 map the front waves left in the other of two LDS buffers.  Each SIMD then holds one front and one back
+// wave whose matrix and VALU phases interleave by construction; a front wave keeps 44 registers of weights, a back wave 36.  Two workgroup
+// barriers per period, executed by every wave whether or not it has a tile (the work is guarded, never the barriers):
+//   front: conv0(t+1)                      | B_a | conv1(t+1) -> C1[(t+1) & 1]; patch of t+2 -> LDS; prefetch t+3 | B_b
+//   back:  stores of t-1; conv2(t) cols 0,1 | B_a | conv2(t) col 2; pool -> staging                                | B_b
+template <int C2P, int PY>
+__global__ void __launch_bounds__(512, 2) scrfd_stem_roles(const StemRArgs a) {
+    constexpr int R2 = 2 * PY + 1, R1 = R2 + 2, R0 = R2 + 4, RI = 2 * R0 + 1;
+    constexpr int N0 = R0 * CW0, NF0 = (N0 + 15) / 16;
+    constexpr int NF2 = C2P / 16, NG2 = 4 / NF2;
+    constexpr int ROWS2 = NG2 == 1 ? R2 : PY + 1;
+    constexpr int PR = PY / NG2;
+    constexpr int ROWS1 = (R1 + 1) / 2;
+    constexpr int ROWB2 = C2P * 2, CPP = ROWB2 / 16;
+    constexpr int IN_BYTES = (RI * RS * 2 + 16 + 255) / 256 * 256;
+    constexpr int C0_BYTES = (R0 + 1) * PW0 * 64, C1_BYTES = (R1 + 1) * PW1 * 64 + 256, STG_BYTES = PY * PXT * ROWB2;
+    constexpr int OFF_IN = 0, OFF_C0 = IN_BYTES, OFF_C1 = OFF_C0 + C0_BYTES, OFF_STG = OFF_C1 + 2 * C1_BYTES, OFF_BIAS = OFF_STG + STG_BYTES;
+    constexpr int ZD = RI * RS / 2;
+    static_assert(PY % 2 == 0 && OFF_BIAS + 512 <= 160 * 1024, "LDS budget");
+    constexpr int NDW = RI * DROW, DPT = (NDW + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, gw = wave & 3, gtid = tid & 255;      // role 0 = front (conv0 + conv1), 1 = back (conv2 + pool + stores)
+    const int frow = lane & 15, fq = lane >> 4;
+    const int f1 = gw & 1, g1 = gw >> 1, f2 = gw % NF2, g2 = gw / NF2;
+
+    // ---- weights -> registers: a front wave holds conv0's two fragments and conv1's nine, a back wave conv2's nine (in the same array) ----
+    half8 w0f[2], wk[9];
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = fq * 8 + j, dy = k / 10, e = k - dy * 10;
+            w0f[f][j] = (role == 0 && k < 30 && e >= 1) ? a.w0[(f * 16 + frow) * 32 + dy * 9 + e - 1] : (_Float16)0.f;
+        }
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+        wk[t] = role == 0 ? *(const half8 *)(a.w1 + ((f1 * 16 + frow) * 9 + t) * 32 + fq * 8) : *(const half8 *)(a.w2 + ((f2 * 16 + frow) * 9 + t) * 32 + fq * 8);
+    float *sB = (float *)(smem + OFF_BIAS);
+    if (tid < 32) { sB[tid] = a.b0[tid]; sB[32 + tid] = a.b1[tid]; }
+    if (tid < C2P) sB[64 + tid] = a.b2[tid];
+    if (tid < 4) ((unsigned *)(smem + OFF_IN))[ZD + tid] = 0u;
+    int rel[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int d = fq * 4 + j, dy = d / 5;
+        rel[j] = dy * (RS / 2) + (d - dy * 5);
+    }
+
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    auto decode = [&](int tile, int &n, int &ty, int &tx) {
+        n = tile / tiles_per_img;
+        const int r = tile - n * tiles_per_img;
+        ty = r / a.tiles_x; tx = r - ty * a.tiles_x;
+    };
+    unsigned pre[DPT];
+    unsigned pre_ok = 0;
+    auto prefetch = [&](int tile) {                             // (front threads only: gtid indexes the patch)
+        int n, ty, tx;
+        decode(tile, n, ty, tx);
+        const int iy0 = 4 * PY * ty - 7, bx0 = 72 * tx - 24, rowbytes = a.W * 3;
+        const uint8_t *base = a.img + (size_t)n * a.H * rowbytes;
+        pre_ok = 0;
+#pragma unroll
+        for (int i = 0; i < DPT; i++) {
+            const int d = gtid + 256 * i;
+            const int pr = d / DROW, dc = d - pr * DROW;
+            const int iy = iy0 + pr, bx = bx0 + dc * 4;
+            const bool in = d < NDW && (unsigned)iy < (unsigned)a.H && bx >= 0 && bx + 4 <= rowbytes;
+            pre[i] = in ? *(const unsigned *)(base + (size_t)iy * rowbytes + bx) : 0u;
+            pre_ok |= in ? (1u << i) : 0u;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < DPT; i++) {
+            const int d = gtid + 256 * i;
+            if (d < NDW) {
+                const int pr = d / DROW, dc = d - pr * DROW;
+                const unsigned v = pre[i];
+                half4 h;
+                h[0] = (_Float16)fmaf((float)(v & 0xFF), 2.f, -255.f);
+                h[1] = (_Float16)fmaf((float)((v >> 8) & 0xFF), 2.f, -255.f);
+                h[2] = (_Float16)fmaf((float)((v >> 16) & 0xFF), 2.f, -255.f);
+                h[3] = (_Float16)fmaf((float)(v >> 24), 2.f, -255.f);
+                if (!((pre_ok >> i) & 1u)) h = half4{0, 0, 0, 0};
+                *(half4 *)(smem + OFF_IN + (pr * RS + dc * 4) * 2) = h;
+            }
+        }
+    };
+    auto make_pb = [&](int rot, int off, int (&pb)[2][4]) {
+#pragma unroll
+        for (int par = 0; par < 2; par++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                pb[par][c] = frow * 64 + ((fq ^ ((((frow + par) >> 1) + c + rot) & 3)) << 4) + off;
+                asm volatile("" : "+v"(pb[par][c]));
+            }
+    };
+    constexpr int NACC = ROWS2 > ROWS1 ? ROWS2 : ROWS1;
+    f32x4 acc[NACC];
+    // tap columns dx0 .. dx1 - 1 of ROWS output rows
+    auto conv_cols = [&](const int (&pb)[2][4], auto rows_tag, auto pw_tag, int dx0, int dx1) {
+        constexpr int ROWS = decltype(rows_tag)::value, PWV = decltype(pw_tag)::value, PH = ROWS + 2;
+        constexpr int PD = STEM_PD;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            if (dx < dx0 || dx >= dx1) continue;
+            half8 pq[PD + 1];
+            auto load_p = [&](int r, int set) {
+                const int K = r * PWV + dx;
+                pq[set] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + K * 64));
+            };
+#pragma unroll
+            for (int r = 0; r < PD; r++) load_p(r, r % (PD + 1));
+#pragma unroll
+            for (int r = 0; r < PH; r++) {
+                if (r + PD < PH) load_p(r + PD, (r + PD) % (PD + 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    const int mi = r - dy;
+                    if (mi < 0 || mi >= ROWS) continue;
+                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk[dy * 3 + dx], pq[r % (PD + 1)], acc[mi], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    using std::integral_constant;
+
+    const int my_tiles = (int)blockIdx.x < a.n_tiles ? (a.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto tile_of = [&](int i) { return (int)blockIdx.x + i * (int)gridDim.x; };
+    if (role == 0 && my_tiles > 0) {
+        prefetch(tile_of(0));
+        commit();
+        if (my_tiles > 1) prefetch(tile_of(1));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                            // the first patch, the bias table, the zero dword
+
+    for (int p = 0; p <= my_tiles + 1; p++) {
+        // ================= first half of the period =================
+        if (role == 0) {
+            if (p < my_tiles && !(a.ablate & 1)) {              // ---- conv0 of tile p (the patch was converted in the period before) ----
+                int n, ty, tx;
+                decode(tile_of(p), n, ty, tx);
+                const int oy0 = 2 * ty * PY - 3, ox0 = 2 * tx * PXT - 3;
+                constexpr int MF0 = (NF0 + 3) / 4, FB = 3;
+                const unsigned *ip = (const unsigned *)(smem + OFF_IN);
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const int fr_ = lo & 15, q4 = lo >> 4;
+                f32x4 bias0[2];
+#pragma unroll
+                for (int f = 0; f < 2; f++) bias0[f] = *(const f32x4 *)(sB + f * 16 + q4 * 4);
+#pragma unroll
+                for (int i0 = 0; i0 < MF0; i0 += FB) {
+                    u32x4 pv[FB];
+                    int lin[FB];
+                    bool inside[FB];
+#pragma unroll
+                    for (int i = 0; i < FB; i++) {
+                        const int fi = gw + 4 * (i0 + i);
+                        const int qd = fi * 16 + fr_, q = qd < N0 ? qd : N0 - 1;
+                        const int y = q / CW0, x = q - y * CW0;
+                        const int bdw = y * RS + 3 * x + 1;
+                        pv[i][0] = ip[bdw + rel[0]];
+                        pv[i][1] = ip[bdw + rel[1]];
+                        pv[i][2] = ip[bdw + rel[2]];
+                        pv[i][3] = ip[q4 == 3 ? ZD : bdw + rel[3]];
+                        inside[i] = qd < N0 && (unsigned)(oy0 + y) < (unsigned)a.H1 && (unsigned)(ox0 + x) < (unsigned)a.W1;
+                        lin[i] = qd < N0 ? y * PW0 + x : -1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < FB; i++) {
+                        if (i0 + i >= MF0 || gw + 4 * (i0 + i) >= NF0) continue;
+                        const half8 pf = __builtin_bit_cast(half8, pv[i]);
+#pragma unroll
+                        for (int f = 0; f < 2; f++) {
+                            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[f], pf, c, 0, 0, 0);
+                            half4 h = __builtin_elementwise_max(__builtin_convertvector(c + bias0[f], half4), half4{0, 0, 0, 0});
+                            if (!inside[i]) h = half4{0, 0, 0, 0};
+                            if (lin[i] >= 0) *(half4 *)(smem + OFF_C0 + lin[i] * 64 + (((f * 2 + (q4 >> 1)) ^ swz64(lin[i])) << 4) + (q4 & 1) * 8) = h;
+                        }
+                    }
+                }
+            }
+        } else {
+            if (p >= 2 && !(a.ablate & 8)) {                    // ---- stores of tile p - 2 (staged in the period before) ----
+                int n, ty, tx;
+                decode(tile_of(p - 2), n, ty, tx);
+                const int py0 = ty * PY, px0 = tx * PXT;
+#pragma unroll
+                for (int i = 0; i < (PY * PXT * CPP + 255) / 256; i++) {
+                    const int s_ = gtid + 256 * i;
+                    const int pix = s_ / CPP, c = s_ - pix * CPP;
+                    const int pp = pix / PXT, q = pix - pp * PXT;
+                    const int gy = py0 + pp, gx = px0 + q;
+                    if (s_ < PY * PXT * CPP && gy < a.Hp && gx < a.Wp)
+                        *(u32x4 *)((char *)a.out + (((size_t)n * a.Hp + gy) * a.Wp + gx) * ROWB2 + c * 16) = *(const u32x4 *)(smem + OFF_STG + pix * ROWB2 + c * 16);
+                }
+            }
+            if (p >= 1 && p <= my_tiles && !(a.ablate & 4)) {   // ---- conv2 of tile p - 1, tap columns 0 and 1 ----
+                int pb[2][4];
+                make_pb(0, OFF_C1 + ((p - 1) & 1) * C1_BYTES + g2 * PY * PW1 * 64, pb);
+#pragma unroll
+                for (int r = 0; r < ROWS2; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                conv_cols(pb, integral_constant<int, ROWS2>{}, integral_constant<int, PW1>{}, 0, 2);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();                                          // B_a: conv0's map of tile p is complete; the staged tile p - 2 has been read
+
+        // ================= second half =================
+        if (role == 0) {
+            if (p < my_tiles) {
+                int n, ty, tx;
+                decode(tile_of(p), n, ty, tx);
+                const int oy0 = 2 * ty * PY - 3, ox0 = 2 * tx * PXT - 3;
+                const bool interior = oy0 >= 0 && ox0 >= 0 && oy0 + R0 <= a.H1 && ox0 + CW0 + 1 <= a.W1;
+                if (!(a.ablate & 2)) {                          // ---- conv1 of tile p -> C1[p & 1] ----
+                    const int r_lo = g1 * ROWS1;
+                    int pb[2][4];
+                    make_pb(((r_lo * PW0) >> 1) & 3, OFF_C0 + r_lo * PW0 * 64, pb);
+#pragma unroll
+                    for (int r = 0; r < ROWS1; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    conv_cols(pb, integral_constant<int, ROWS1>{}, integral_constant<int, PW0>{}, 0, 3);
+                    int lo = lane;
+                    asm volatile("" : "+v"(lo));
+                    const int fr = lo & 15, q4 = lo >> 4;
+                    const f32x4 bias1 = *(const f32x4 *)(sB + 32 + f1 * 16 + q4 * 4);
+                    const bool xin = fr < CW1 && (unsigned)(ox0 + 1 + fr) < (unsigned)a.W1;
+                    char *cp = smem + OFF_C1 + (p & 1) * C1_BYTES + (r_lo * PW1 + fr) * 64 + (((f1 * 2 + (q4 >> 1)) ^ swz64(fr)) << 4) + (q4 & 1) * 8;
+#pragma unroll
+                    for (int i = 0; i < ROWS1; i++) {
+                        if (r_lo + i >= R1) continue;
+                        half4 h = __builtin_elementwise_max(__builtin_convertvector(acc[i] + bias1, half4), half4{0, 0, 0, 0});
+                        if (!interior && !(xin && (unsigned)(oy0 + 1 + r_lo + i) < (unsigned)a.H1)) h = half4{0, 0, 0, 0};
+                        *(half4 *)(cp + i * (PW1 * 64)) = h;
+                    }
+                }
+            }
+            if (p + 1 < my_tiles && !(a.ablate & 16)) {          // ---- the patch of tile p + 1 (conv0 of this period is done with the buffer) ----
+                commit();
+                if (p + 2 < my_tiles) prefetch(tile_of(p + 2));
+            }
+        } else {
+            if (p >= 1 && p <= my_tiles && !(a.ablate & 4)) {   // ---- conv2 of tile p - 1, tap column 2; pool; staging ----
+                int n, ty, tx;
+                decode(tile_of(p - 1), n, ty, tx);
+                const int oy0 = 2 * ty * PY - 3, ox0 = 2 * tx * PXT - 3;
+                const bool interior = oy0 >= 0 && ox0 >= 0 && oy0 + R0 <= a.H1 && ox0 + CW0 + 1 <= a.W1;
+                const int r_lo = g2 * PY;
+                int pb[2][4];
+                make_pb(0, OFF_C1 + ((p - 1) & 1) * C1_BYTES + r_lo * PW1 * 64, pb);
+                conv_cols(pb, integral_constant<int, ROWS2>{}, integral_constant<int, PW1>{}, 2, 3);
+                int lo = lane;
+                asm volatile("" : "+v"(lo));
+                const int fr = lo & 15, q4 = lo >> 4;
+                const f32x4 bias2 = *(const f32x4 *)(sB + 64 + f2 * 16 + q4 * 4);
+                const bool xin = fr < CW2 && (unsigned)(ox0 + 2 + fr) < (unsigned)a.W1;
+                const int gy0 = oy0 + 2 + r_lo;
+                if (!interior) {
+                    const float ninf = -__builtin_inff();
+#pragma unroll
+                    for (int i = 0; i < ROWS2; i++)
+                        if (!(xin && (unsigned)(gy0 + i) < (unsigned)a.H1)) acc[i] = f32x4{ninf, ninf, ninf, ninf};
+                }
+                const bool st = (fr & 1) == 0 && fr < 2 * PXT;
+                char *sp = smem + OFF_STG + ((g2 * PR) * PXT + (fr >> 1)) * ROWB2 + (f2 * 16 + q4 * 4) * 2;
+#pragma unroll
+                for (int pp = 0; pp < PR; pp++) {
+                    f32x4 m;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float v = fmaxf(fmaxf(acc[2 * pp][e], acc[2 * pp + 1][e]), acc[2 * pp + 2][e]);
+                        m[e] = fmaxf(fmaxf(v, row_shl<1>(v)), row_shl<2>(v));
+                    }
+                    const half4 h = __builtin_elementwise_max(__builtin_convertvector(m + bias2, half4), half4{0, 0, 0, 0});
+                    if (st) *(half4 *)(sp + pp * (PXT * ROWB2)) = h;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();                                          // B_b: C1[p & 1] and the next patch are complete; tile p - 1 is staged
+    }
+}
+
+template <int C2P, int PY>
+int launch_roles(fid_ctx *ctx, StemRArgs &a) {
+    constexpr int R2 = 2 * PY + 1, R1 = R2 + 2, R0 = R2 + 4, RI = 2 * R0 + 1;
+    constexpr int lds = (RI * RS * 2 + 16 + 255) / 256 * 256 + (R0 + 1) * PW0 * 64 + 2 * ((R1 + 1) * PW1 * 64 + 256) + PY * PXT * C2P * 2 + 512;
+    a.tiles_x = cdiv(a.Wp, PXT); a.tiles_y = cdiv(a.Hp, PY);
+    a.n_tiles = (a.n_tiles) * a.tiles_x * a.tiles_y;
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)scrfd_stem_roles<C2P, PY>, lds));
+    const int grid = std::min(a.n_tiles, ctx->num_cus);
+    hipLaunchKernelGGL((scrfd_stem_roles<C2P, PY>), dim3(grid), dim3(512), lds, ctx->stream, a);
+    FID_HIP(hipGetLastError());
+    return FID_OK;
+}
+
 template <int C2P, int PY>
 int launch_rows(fid_ctx *ctx, StemRArgs &a) {
     constexpr int R2 = 2 * PY + 1, R1 = R2 + 2, R0 = R2 + 4, RI = 2 * R0 + 1;
@@ -380,6 +689,9 @@ int stem_rows_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, cons
     if (const char *e = getenv("FID_STEM_ABLATE")) a.ablate = atoi(e);
     a.stagger = getenv("FID_STEM_STAGGER") ? atoi(getenv("FID_STEM_STAGGER")) : 0;
     const int py = getenv("FID_STEM_PY") ? atoi(getenv("FID_STEM_PY")) : 8;      // (read per launch: the tests switch it)
+    const bool roles = getenv("FID_STEM_ROLES") != nullptr;    // (read per launch: the tests switch it)
+    if (roles && C2p == 64) return launch_roles<64, 8>(ctx, a);
+    if (roles && C2p == 32) return launch_roles<32, 8>(ctx, a);
     if (C2p == 64) return py == 6 ? launch_rows<64, 6>(ctx, a) : launch_rows<64, 8>(ctx, a);
     if (C2p == 32) return py == 6 ? launch_rows<32, 6>(ctx, a) : launch_rows<32, 8>(ctx, a);
     set_error("fused stem: C2p=%d unsupported", C2p);

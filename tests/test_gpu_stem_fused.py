@@ -29,8 +29,8 @@ def stem_net(hw, c0, c2):
 
 
 # kernels: the row-structured stem (csrc/stem_rows.hip, the default) with 8 / 6 pooled rows per tile, and the first design on flattened
-# fragments (csrc/stem_fused.hip, FID_STEM_OLD=1)
-@pytest.mark.parametrize("kernel", ["rows8", "rows6", "flat"])
+# fragments (csrc/stem_fused.hip, FID_STEM_OLD=1); "roles" = the row-structured stem with front / back wave roles (FID_STEM_ROLES=1)
+@pytest.mark.parametrize("kernel", ["rows8", "rows6", "roles", "flat"])
 @pytest.mark.parametrize("hw,c0,c2,batch", [((64, 64), 28, 56, 3), ((96, 160), 28, 56, 2), ((72, 100), 12, 24, 2),
                                              ((320, 320), 28, 56, 1), ((100, 76), 24, 24, 3), ((640, 640), 28, 56, 1)])
 def test_fused_stem_matches_oracle_and_unfused(ctx, monkeypatch, kernel, hw, c0, c2, batch):
@@ -43,6 +43,8 @@ def test_fused_stem_matches_oracle_and_unfused(ctx, monkeypatch, kernel, hw, c0,
     assert lower(net, P).op_names == ["stem.fused"]
     if kernel == "flat":
         monkeypatch.setenv("FID_STEM_OLD", "1")
+    elif kernel == "roles":                    # conv0 + conv1 waves one tile ahead of conv2 + pool waves (scrfd_stem_roles)
+        monkeypatch.setenv("FID_STEM_ROLES", "1")
     else:
         monkeypatch.setenv("FID_STEM_PY", kernel[4:])
     cn = CompiledNet(ctx, net, P, max_batch=batch)
