@@ -784,8 +784,13 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
     {
         hipDeviceProp_t prop;
         FID_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        // ISA name without its feature suffixes + CU count: the marketing name and the ":sramecc+:xnack-" tail vary with the driver stack
+        // and with tools that wrap the process (under rocprofv3 the r3 plan did not match and every net re-tuned inside the profile)
+        char arch[128];
+        snprintf(arch, sizeof(arch), "%s", prop.gcnArchName);
+        if (char *c = strchr(arch, ':')) *c = 0;
         char key[256];
-        snprintf(key, sizeof(key), "%s/%s/cus%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+        snprintf(key, sizeof(key), "%s/cus%d", arch, prop.multiProcessorCount);
         for (char *c = key; *c; c++)
             if (*c == '|' || *c == '\n') *c = '_';
         net->device_key = key;
@@ -796,12 +801,18 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
         h = fnv1a(&rev, sizeof(rev), h);
         net->table_hash = h;
     }
+    int n_plan = -1;
+    const char *plan_file = nullptr;
     if (const char *e = getenv("FID_PLAN")) {                 // load + append every new pick (plan generation: tools/make_plan.sh)
         net->plan_path = e;
-        (void)plan_load(net, e, nullptr);
+        plan_file = e;
+        (void)plan_load(net, e, &n_plan);
     } else if (const char *e = getenv("FID_PLAN_RO")) {        // load only: a tracked plan file is never written by a run (bench.py)
-        (void)plan_load(net, e, nullptr);
+        plan_file = e;
+        (void)plan_load(net, e, &n_plan);
     }
+    if (getenv("FID_TUNE_LOG"))
+        fprintf(stderr, "[plan] device key %s, table %016llx: %d picks from %s\n", net->device_key.c_str(), net->table_hash, n_plan, plan_file ? plan_file : "(no plan file)");
     *out = net;
     return FID_OK;
 }
