@@ -156,9 +156,11 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
 
     f32x4 acc[8];
     constexpr int PD = 2;
-    // one 32-channel chunk of one conv: ROWS output rows of this wave from ROWS + 2 fragment rows x 3 tap columns
-    auto conv_chunk = [&](int base_off, auto rows_tag, auto pw_tag, const half8 *wv, auto &&col_hook) {
-        constexpr int ROWS = decltype(rows_tag)::value, PWV = decltype(pw_tag)::value, PH = ROWS + 2;
+    // one conv: ROWS output rows of this wave from ROWS + 2 fragment rows x 3 tap columns x 2 chunks of 32 channels.  The six (chunk, column)
+    // passes are ONE flattened sequence of fragment rows, read PD rows ahead ACROSS the pass boundaries: a pass that starts its own
+    // read-ahead waits an LDS round trip (~150 cycles) with the matrix pipe idle -- six times per conv, twelve per item.
+    auto conv_phase = [&](int base_off, auto rows_tag, auto pw_tag, auto cs_tag, const half8 *wv, auto &&col_hook) {
+        constexpr int ROWS = decltype(rows_tag)::value, PWV = decltype(pw_tag)::value, CS = decltype(cs_tag)::value, PH = ROWS + 2, NQ = 6 * PH;
         int pb[2][4];
 #pragma unroll
         for (int par = 0; par < 2; par++)
@@ -167,28 +169,27 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
                 pb[par][c] = pbase[par][c] + base_off;
                 asm volatile("" : "+v"(pb[par][c]));
             }
+        half8 pq[PD + 1];
+        auto load_p = [&](int q) {                              // q = (chunk * 3 + dx) * PH + fragment row
+            const int pass = q / PH, r = q - pass * PH, ck = pass / 3, dx = pass - ck * 3;
+            const int K = r * PWV + dx;
+            pq[q % (PD + 1)] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + (K * 64 + ck * CS)));
+        };
 #pragma unroll
-        for (int dx = 0; dx < 3; dx++) {
-            col_hook(dx);
-            half8 pq[PD + 1];
-            auto load_p = [&](int r, int set) {
-                const int K = r * PWV + dx;
-                pq[set] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + K * 64));
-            };
+        for (int q = 0; q < PD; q++) load_p(q);
 #pragma unroll
-            for (int r = 0; r < PD; r++) load_p(r, r % (PD + 1));
+        for (int q = 0; q < NQ; q++) {
+            const int pass = q / PH, r = q - pass * PH, ck = pass / 3, dx = pass - ck * 3;
+            if (r == 0) col_hook(pass);
+            if (q + PD < NQ) load_p(q + PD);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < PH; r++) {
-                if (r + PD < PH) load_p(r + PD, (r + PD) % (PD + 1));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int dy = 0; dy < 3; dy++) {
-                    const int mi = r - dy;
-                    if (mi < 0 || mi >= ROWS) continue;
-                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[dy * 3 + dx], pq[r % (PD + 1)], acc[mi], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int dy = 0; dy < 3; dy++) {
+                const int mi = r - dy;
+                if (mi < 0 || mi >= ROWS) continue;
+                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ck * 9 + dy * 3 + dx], pq[q % (PD + 1)], acc[mi], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     using std::integral_constant;
@@ -227,16 +228,14 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
         decode_tile(item, n, ty, tx);
         const bool nlive = it + 1 < my_items;
         decode_tile(nlive ? item + gridDim.x : 0, nn, nty, ntx);
-        auto fetch_hook0 = [&](int dx) { issue_piece(dx, nn, nty, ntx, nlive, buf ^ 1); };
-        auto fetch_hook1 = [&](int dx) { issue_piece(3 + dx, nn, nty, ntx, nlive, buf ^ 1); };
+        auto fetch_hook = [&](int pass) { issue_piece(pass, nn, nty, ntx, nlive, buf ^ 1); };      // one piece of the next patch per (chunk, column) pass
 
         // ================= A: conv1 on the 16x16 region (rows 8 rg .. 8 rg + 7 here) =================
 #pragma unroll
         for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(a.ablate & 1)) {
             const int xo = OFF_X + buf * X_ITEM + rg * (8 * PW * 64);
-            conv_chunk(xo, integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1, fetch_hook0);
-            conv_chunk(xo + P_BYTES, integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1 + 9, fetch_hook1);
+            conv_phase(xo, integral_constant<int, 8>{}, integral_constant<int, PW>{}, integral_constant<int, P_BYTES>{}, w1, fetch_hook);
         } else {
 #pragma unroll
             for (int k = 0; k < MAX_P; k++) issue_piece(k, nn, nty, ntx, nlive, buf ^ 1);
@@ -275,8 +274,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
         for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(a.ablate & 2)) {
             const int mo = OFF_MID + rg * (7 * MW * 64);
-            conv_chunk(mo, integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2, no_hook);
-            conv_chunk(mo + MID_CH, integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2 + 9, no_hook);
+            conv_phase(mo, integral_constant<int, 7>{}, integral_constant<int, MW>{}, integral_constant<int, MID_CH>{}, w2, no_hook);
         }
         {
             int lo = lane;
@@ -286,11 +284,16 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
             const int g0 = (cw & 1) * 2 + (q4 >> 1);
             const char *xp = smem + OFF_X + buf * X_ITEM + (cw >> 1) * P_BYTES + (q4 & 1) * 8;
             char *sp = smem + OFF_STG + fr * ROWB + (((cw * 2 + (q4 >> 1) + fr) % CPX) << 4) + (q4 & 1) * 8;   // chunk rotated by the pixel column
+            half4 rs[7];                                        // all residual reads first: one LDS round trip, not one per row (the staging writes below may alias for the compiler)
 #pragma unroll
             for (int i = 0; i < 7; i++) {
                 const int r = rg * 7 + i, lin = (r + 2) * PW + fr + 2;
-                const half4 rs = *(const half4 *)(xp + lin * 64 + ((g0 ^ swz64(lin)) << 4));
-                f32x4 v = acc[i] + bias2 + __builtin_convertvector(rs, f32x4);
+                rs[i] = *(const half4 *)(xp + lin * 64 + ((g0 ^ swz64(lin)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const int r = rg * 7 + i;
+                f32x4 v = acc[i] + bias2 + __builtin_convertvector(rs[i], f32x4);
                 half4 h = __builtin_convertvector(v, half4);
                 if (a.act2 == ACT_RELU) h = __builtin_elementwise_max(h, half4{0, 0, 0, 0});
                 *(half4 *)(sp + r * (16 * ROWB)) = h;
