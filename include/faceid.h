@@ -89,7 +89,10 @@ int fid_event_elapsed_ms(fid_ctx *ctx, int slot_start, int slot_stop, float *ms)
  * (format documented in csrc/net.h): `ops` is n_ops x FID_OP_WORDS int32, `tensors` is
  * n_tensors x FID_TENSOR_WORDS int32, `blob` holds packed fp16 weights + fp32 epilogue tables.
  * Input of fid_net_run: uint8 BGR images [batch, H, W, 3]; the blob conversion
- * (cv2.dnn.blobFromImage(s), scrfd.py:76-82 / arcface.py:44-50) is fused into the first conv. */
+ * (cv2.dnn.blobFromImage(s), scrfd.py:76-82 / arcface.py:44-50) is fused into the first conv.
+ * A net belongs to the context it was created with: its activation slots, lazily built weight repackings and kernel plans
+ * are per net and unsynchronised, so run one net from ONE context (several host threads may share that context: its mutex
+ * serialises them); a second stream needs its own fid_net (bench.py: one per lane). */
 #define FID_OP_WORDS 32
 #define FID_TENSOR_WORDS 8
 int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *tensors,
@@ -107,9 +110,10 @@ int fid_net_tensor(fid_net *net, int tensor_id, void **dptr, int dims[4], int *d
 int fid_net_run_profiled(fid_ctx *ctx, fid_net *net, const uint8_t *images_dev, int batch,
                          float *op_ms);
 /* Kernel plans (per conv op and batch size the executor times its candidate kernels at first use and keeps the fastest).
- * Text lines keyed by device name + layer-table hash; a loaded plan replaces the timing, so two boxes run the same
+ * Text lines keyed by ISA name + CU count + layer-table hash (incl. the library's candidate-set revision); every line is checked
+ * against this library's candidates before its first use; a loaded plan replaces the timing, so two boxes run the same
  * kernels / fp32 summation orders and return bit-identical outputs.  Environment FID_PLAN=<file>: load at
- * fid_net_create, append every new pick.  (No reference analogue: onnxruntime picks its kernels internally.) */
+ * fid_net_create, append every new pick; FID_PLAN_RO=<file>: load only.  (No reference analogue: onnxruntime picks its kernels internally.) */
 int fid_net_plan_save(fid_net *net, const char *path);
 int fid_net_plan_load(fid_net *net, const char *path, int *n_loaded);
 /* algorithmic cost of one image through the net: multiply-accumulates (true channel counts) */

@@ -47,6 +47,7 @@ struct KSArgs {
     unsigned in_bytes, out_bytes, w_bytes;
     int ncls;             // bias classes: 9 with CF_BORDER, 1 with a plain bias, 0 without
     int rev;              // ConvArgs::rev
+    int ablate;           // FID_KS_ABLATE timing experiments (wrong results): 1 no step barrier, 2 no patch pieces, 4 no weight reloads, 8 no epilogue, 16 no matrix work
 };
 
 template <int TH>
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
             int pk = p_pk[k];
             asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
             const int py = pk & 255, iy = c.y0 + py, ix = c.x0 + ((pk >> 8) & 255);
-            const bool in = c.n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const bool in = c.n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 2);
             const unsigned vo = in ? (unsigned)((((c.n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
             char *d = j < N_PIECES ? dst + j * 1024 : smem + OFF_SPARE;      // surplus piece: zeros into the spare KB
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)d, 16, vo, 0, 0, 0);
@@ -321,7 +322,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
     int ck = 0, item = bid, slot = 0;
     for (int s = 0; s < n_steps; s++) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_TOP) : "memory");      // my pieces of step s have landed
-        raw_barrier();                                          // ... everybody's; everyone is done with the other slot (and with the tables of the item before)
+        if (!(a.ablate & 1)) raw_barrier();                     // ... everybody's; everyone is done with the other slot (and with the tables of the item before)
         if (s + 1 < n_steps) { issue_patches(cf, slot ^ 1); cursor_next(cf); }
         else issue_patches(none, slot ^ 1);
         if (ck == 0) {
@@ -332,19 +333,19 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_COL) : "memory");
         asm volatile("" : "+v"(w[0]), "+v"(w[3]), "+v"(w[6]));
         __builtin_amdgcn_sched_barrier(0);
-        compute_col(so, 0);
-        load_col(w_cb, w_ck, 0, w[0], w[3], w[6]);              // (past the last step these fetch a valid, unused block: the count stays exact)
+        if (!(a.ablate & 16)) compute_col(so, 0);
+        if (!(a.ablate & 4)) load_col(w_cb, w_ck, 0, w[0], w[3], w[6]);              // (past the last step these fetch a valid, unused block: the count stays exact)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_COL) : "memory");
         asm volatile("" : "+v"(w[1]), "+v"(w[4]), "+v"(w[7]));
         __builtin_amdgcn_sched_barrier(0);
-        compute_col(so, 1);
-        load_col(w_cb, w_ck, 1, w[1], w[4], w[7]);
+        if (!(a.ablate & 16)) compute_col(so, 1);
+        if (!(a.ablate & 4)) load_col(w_cb, w_ck, 1, w[1], w[4], w[7]);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_COL) : "memory");
         asm volatile("" : "+v"(w[2]), "+v"(w[5]), "+v"(w[8]));
         __builtin_amdgcn_sched_barrier(0);
-        compute_col(so, 2);
+        if (!(a.ablate & 16)) compute_col(so, 2);
         if (++ck == a.n_steps_item) {
-            epilogue(item, smem + so);
+            if (!(a.ablate & 8)) epilogue(item, smem + so);
             ck = 0; item += gridDim.x;
             if (s + 1 < n_steps) {                              // the next item's cout block (the same one whenever the grid is a multiple of the block count)
                 int tile, cb;
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
                 if (cb != tab_cb) { tab_cb = cb; fill_tables(cb); }      // (published by the next step's barrier; read an item later)
             }
         }
-        load_col(w_cb, w_ck, 2, w[2], w[5], w[8]);
+        if (!(a.ablate & 4)) load_col(w_cb, w_ck, 2, w[2], w[5], w[8]);
         w_next();
         slot ^= 1;
     }
@@ -405,6 +406,8 @@ int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c) {
     a.out_bytes = (unsigned)ob;
     a.w_bytes = (unsigned)repack_bytes(2, c.Cout_p, c.Cin_p);
     a.ncls = c.bias ? ((c.flags & CF_BORDER) ? 9 : 1) : 0;
+    static const int ablate = getenv("FID_KS_ABLATE") ? atoi(getenv("FID_KS_ABLATE")) : 0;
+    a.ablate = ablate;
     if (TH == 10) return ks_launch_t<10>(ctx, a);
     if (TH == 14) return ks_launch_t<14>(ctx, a);
     return ks_launch_t<16>(ctx, a);
