@@ -155,7 +155,10 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
         for (int c = 0; c < 4; c++) pbase[par][c] = frow * 64 + ((fq ^ ((((frow + par) >> 1) + c) & 3)) << 4);
 
     f32x4 acc[8];
-    constexpr int PD = 2;
+#ifndef BB_PD
+#define BB_PD 2
+#endif
+    constexpr int PD = BB_PD;                                   // fragment rows read ahead
     // one conv: ROWS output rows of this wave from ROWS + 2 fragment rows x 3 tap columns x 2 chunks of 32 channels.  The six (chunk, column)
     // passes are ONE flattened sequence of fragment rows, read PD rows ahead ACROSS the pass boundaries: a pass that starts its own
     // read-ahead waits an LDS round trip (~150 cycles) with the matrix pipe idle -- six times per conv, twelve per item.
