@@ -63,8 +63,12 @@ __device__ __forceinline__ float row_shl(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + N, 0xF, 0xF, true));
 }
 
+#ifndef STEM_WPS
+#define STEM_WPS 2
+#endif
+// (PY = 6 tiles need 50 KB of LDS: three workgroups fit a CU if the registers allow three waves per SIMD: -DSTEM_WPS=3 forces <= 168 VGPRs there)
 template <int C2P, int PY>
-__global__ void __launch_bounds__(256, 2) scrfd_stem_rows(const StemRArgs a) {
+__global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(const StemRArgs a) {
     constexpr int R2 = 2 * PY + 1, R1 = R2 + 2, R0 = R2 + 4, RI = 2 * R0 + 1;
     constexpr int N0 = R0 * CW0, NF0 = (N0 + 15) / 16;             // conv0: flattened pixels / fragments
     constexpr int NF2 = C2P / 16, NG2 = 4 / NF2;                   // conv2: cout fragments (4 | 2), row groups (1 | 2)
@@ -77,6 +81,7 @@ __global__ void __launch_bounds__(256, 2) scrfd_stem_rows(const StemRArgs a) {
     constexpr int OFF_IN = 0, OFF_C0 = IN_BYTES, OFF_C1 = OFF_C0 + C0_BYTES, OFF_STG = OFF_C1 + C1_BYTES, OFF_BIAS = OFF_STG + STG_BYTES;
     constexpr int ZD = RI * RS / 2;                                // dword index of the zero dword behind the patch
     static_assert(PY % 2 == 0 && OFF_BIAS + 512 <= 80 * 1024, "two workgroups per CU");
+    static_assert(PY != 6 || STEM_WPS < 3 || OFF_BIAS + 512 <= 53 * 1024, "three workgroups per CU");
     constexpr int NDW = RI * DROW, DPT = (NDW + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -669,7 +674,7 @@ int launch_rows(fid_ctx *ctx, StemRArgs &a) {
     a.tiles_x = cdiv(a.Wp, PXT); a.tiles_y = cdiv(a.Hp, PY);
     a.n_tiles = (a.n_tiles) * a.tiles_x * a.tiles_y;              // (n_tiles holds the batch size on entry)
     FID_TRY(ensure_dyn_lds(ctx, (const void *)scrfd_stem_rows<C2P, PY>, lds));
-    const int grid = std::min(a.n_tiles, ctx->num_cus * 2);
+    const int grid = std::min(a.n_tiles, ctx->num_cus * (PY == 6 ? STEM_WPS : 2));
     hipLaunchKernelGGL((scrfd_stem_rows<C2P, PY>), dim3(grid), dim3(256), lds, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
