@@ -748,7 +748,10 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
                         (op[W_WOFF] < 0 || (size_t)op[W_WOFF] + (size_t)op[W_WBYTES] <= blob_bytes) &&
                         (op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_STEMFUSED) == (op[W_SRC] == -1) &&
                         (op[W_TYPE] != OP_BBLOCK || (op[W_B_W1] >= 0 && op[W_B_W2] >= 0 && (size_t)std::max(op[W_B_W1], op[W_B_W2]) + 147456 <= blob_bytes &&
-                                                     op[W_B_B1] >= 0 && op[W_B_B2] >= 0 && (size_t)std::max(op[W_B_B1], op[W_B_B2]) + 256 <= blob_bytes));
+                                                     op[W_B_B1] >= 0 && (size_t)op[W_B_B1] + ((op[W_FLAGS] & CF_BORDER) ? 9 : 1) * 256 <= blob_bytes &&
+                                                     op[W_B_B2] >= 0 && (size_t)op[W_B_B2] + 256 <= blob_bytes &&
+                                                     (op[W_B_ACT1] == ACT_RELU || (op[W_B_ACT1] == ACT_PRELU && op[W_B_S1] >= 0 && (size_t)op[W_B_S1] + 256 <= blob_bytes)))) &&
+                        (op[W_TYPE] != OP_DWPW || (op[W_D_WOFF] >= 0 && op[W_D_BOFF] >= 0 && op[W_WOFF] >= 0 && (op[W_D_ACT] != ACT_PRELU || op[W_D_SOFF] >= 0)));
         if (!ok) {
             delete net;
             set_error("op %d: bad record", oi);
