@@ -51,6 +51,7 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split);
 #include <vector>
 std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split);
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan);
+float conv_plan_cu_share(const ConvArgs &a, const ConvPlan &plan, int num_cus);      // fraction of the CUs the launch occupies (1: all / not modelled)
 // does the kernel `plan` names honour ConvArgs::rev?
 inline bool conv_walks_reverse(const ConvPlan &plan) { return plan.gen == 9; }
 // alternate weight packing a plan's kernel wants in ConvArgs::w_alt (0 = none); repack.hip builds it
@@ -88,6 +89,7 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident
 
 // conv_ks.hip (generation 9, ns = 6): conv3x3_wr's one-tile x 64-cout item with the K axis split over two wave groups (few tiles: one item per CU); needs w_alt (kind 2)
 bool conv_ks_applicable(const ConvArgs &a);
+bool conv_ks_mosaic(const ConvArgs &a);      // 7x7 maps: four images share a 16x16 tile
 int conv_ks_launch(fid_ctx *ctx, const ConvArgs &a);
 
 // conv_s2.hip (generation 10): 3x3 / stride 2 with parity-plane patches and resident weights (64 / 96 input channels); needs w_alt (kind 2)

@@ -837,6 +837,10 @@ std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow
         if (conv_wr_resident_ok(a)) { d.bm = 256; d.bn = a.Cout_p; d.ns = 1; out.push_back(d); }   // the layer's weights resident in registers
         if (conv_ks_applicable(a)) { d.bm = 256; d.bn = 64; d.ns = 6; out.push_back(d); }           // one tile x 64 couts, the K axis split over two wave groups (conv_ks.hip)
     }
+    else if (conv_ks_applicable(a)) {                  // 7x7 maps: four images per 16x16 tile (conv_ks.hip, MOSAIC)
+        ConvPlan d{};
+        d.gen = 9; d.ksplit = 1; d.bk = 32; d.bm = 256; d.bn = 64; d.ns = 6; out.push_back(d);
+    }
     if (conv_pc_applicable(a)) {
         ConvPlan d{};
         d.gen = 5; d.ksplit = 1; d.bm = 256; d.bk = 32;
@@ -905,6 +909,21 @@ int plan_alt_kind(const ConvPlan &plan) {
     if (plan.gen == 9 || plan.gen == 10) return 2;
     if (plan.gen == 11) return 3;
     return 0;
+}
+
+// The fraction of the chip's CUs a candidate's launch occupies (1 = all of them, or a family whose grid is not modelled here).  The
+// autotuner can weigh it in (FID_TUNE_SHARE, net.hip): with two batches in flight on two streams a launch that holds half the CUs
+// for the same time leaves the other half to the other lane.
+float conv_plan_cu_share(const ConvArgs &a, const ConvPlan &plan, int num_cus) {
+    long long wgs = -1;
+    if (plan.gen == 1 || plan.gen == 2 || plan.gen == 11) wgs = (long long)cdiv(a.M, plan.bm) * cdiv(a.Cout_p, plan.bn) * std::max(1, plan.ksplit);
+    else if (plan.gen == 9 && plan.ns == 6 && conv_ks_mosaic(a)) wgs = (long long)cdiv(a.M / 49, 4) * cdiv(a.Cout_p, 64);
+    else if (plan.gen == 9 && plan.ns != 1) {
+        const long long tiles = (long long)(a.M / (a.Ho * a.Wo)) * cdiv(a.Ho, 14) * cdiv(a.Wo, 14);      // (14 / 16-row tiles: the smaller count)
+        wgs = cdiv((int)tiles, plan.bm / 256) * cdiv(a.Cout_p, plan.bn);
+    }
+    if (wgs < 0 || wgs >= num_cus) return 1.f;
+    return (float)wgs / (float)num_cus;
 }
 
 int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {

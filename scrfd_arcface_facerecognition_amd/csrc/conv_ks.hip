@@ -47,10 +47,14 @@ struct KSArgs {
     unsigned in_bytes, out_bytes, w_bytes;
     int ncls;             // bias classes: 9 with CF_BORDER, 1 with a plain bias, 0 without
     int rev;              // ConvArgs::rev
+    int n_img;            // images (MOSAIC: the faces four of which share a tile)
     int ablate;           // FID_KS_ABLATE timing experiments (wrong results): 1 no step barrier, 2 no patch pieces, 4 no weight reloads, 8 no epilogue, 16 no matrix work
 };
 
-template <int TH>
+// MOSAIC (TH = 16, 7x7 maps -- IResNet's last stage): a tile is a 2 x 2 mosaic of four images, image (r, c) of the mosaic at tile pixels
+// [8r, 8r + 7) x [8c, 8c + 7); tile row / column 7 and 15 are zero gutters (the zero padding between neighbours: never fetched, computed and
+// dropped), so one 16-pixel matrix column carries two images and an item's 64 x 9 Cin weights serve four images instead of one.
+template <int TH, bool MOSAIC>
 __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
     constexpr int TW = TH, PH = TH + 2, NPIX = PH * PW, RH = TH / 2;
     constexpr int P_BLKS = (NPIX * 64 + 1023) / 1024, P_BYTES = P_BLKS * 1024, SLOT = KS * P_BYTES, NS = 2;
@@ -75,6 +79,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         cb = item - tile * a.n_cblk;
     };
     auto decode_tile = [&](int t, int &n, int &ty, int &tx) {
+        if (MOSAIC) { n = t; ty = 0; tx = 0; return; }           // n = the mosaic; its images are 4n .. 4n + 3
         n = fastdiv(t, a.d_tpi);
         const int r = t - n * a.tiles_per_img;
         ty = fastdiv(r, a.d_tx); tx = r - ty * a.tiles_x;
@@ -121,8 +126,16 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
             int pk = p_pk[k];
             asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
             const int py = pk & 255, iy = c.y0 + py, ix = c.x0 + ((pk >> 8) & 255);
-            const bool in = c.n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 2);
-            const unsigned vo = in ? (unsigned)((((c.n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
+            bool in;
+            unsigned vo;
+            if (MOSAIC) {
+                const int img = c.n * 4 + (iy >> 3) * 2 + (ix >> 3), ly = iy & 7, lx = ix & 7;
+                in = c.n >= 0 && py != 255 && (unsigned)iy < 16u && (unsigned)ix < 16u && ly < 7 && lx < 7 && img < a.n_img && !(a.ablate & 2);
+                vo = in ? (unsigned)((((img * 7 + ly) * 7 + lx) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
+            } else {
+                in = c.n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 2);
+                vo = in ? (unsigned)((((c.n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
+            }
             char *d = j < N_PIECES ? dst + j * 1024 : smem + OFF_SPARE;      // surplus piece: zeros into the spare KB
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)d, 16, vo, 0, 0, 0);
         }
@@ -214,8 +227,10 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         for (int i = 0; i < RH; i++) *(f32x4 *)(ex_w + i * 1024) = kg ? acc[i] : acc[RH + i];
         const int co0 = cb * CBW + cw * 16 + q4 * 4, cl = cw * 16 + q4 * 4;
         const bool co_ok = co0 < a.Cout_p;
-        const int oy0 = ty * TH + kg * RH, ox = tx * TW + fr;
-        const bool t_ok = tile < a.n_tiles && co_ok && fr < TW && ox < a.W;
+        // MOSAIC: wave group kg finishes mosaic row kg (RH = 8 tile rows = one image's 7 rows + the gutter); the lane's column picks the image
+        if (MOSAIC) n = n * 4 + kg * 2 + (fr >> 3);
+        const int oy0 = MOSAIC ? 0 : ty * TH + kg * RH, ox = MOSAIC ? (fr & 7) : tx * TW + fr;
+        const bool t_ok = tile < a.n_tiles && co_ok && fr < TW && ox < a.W && (!MOSAIC || n < a.n_img);
         const unsigned rstride = (unsigned)(a.W * a.Cout_p * 2);
         const unsigned t_base = (unsigned)((((n * a.H + oy0) * a.W + ox) * a.Cout_p + co0) * 2);
         u32x2 rr[RH];
@@ -258,9 +273,20 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         asm volatile("" : "+v"(t2));
         const int q0 = t2 >> 3, c = t2 & 7;
         const int pr0 = q0 >> 4, pc = q0 & 15;
-        const int oxx = tx * TW + pc, co = cb * CBW + c * 8;
+        const int oxx = MOSAIC ? (pc & 7) : tx * TW + pc, co = cb * CBW + c * 8;
         const bool okc = tile < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p;
         const char *lsrc = stage + q0 * ROWB + (((c + pc) % CPX) << 4);
+        if (MOSAIC) {       // rounds 0, 1: mosaic row 0 (image rows pr0, 4 + pr0), rounds 2, 3: mosaic row 1
+            const int img0 = tile * 4 + (pc >> 3);
+#pragma unroll
+            for (int i = 0; i < ST_I; i++) {
+                const int img = img0 + (i >> 1) * 2, ly = 4 * (i & 1) + pr0;
+                const bool ok = okc && ly < 7 && img < a.n_img;
+                const u32x4 v = *(const u32x4 *)(lsrc + i * (64 * ROWB));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, ok ? (unsigned)((((img * 7 + ly) * 7 + oxx) * a.Cout_p + co) * 2) : OOB, 0, 0);
+            }
+            return;
+        }
         const unsigned g0 = (unsigned)((((n * a.H + ty * TH + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
 #pragma unroll
         for (int i = 0; i < ST_I; i++) {
@@ -360,23 +386,32 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the surplus loads target registers / LDS of this wave: drain before exit
 }
 
-template <int TH>
+template <int TH, bool MOSAIC = false>
 static int ks_launch_t(fid_ctx *ctx, KSArgs &a) {
     constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     const int LDS = 2 * KS * P_BYTES + 1024 + NWT * (TH / 2) * 1024 + (a.ncls + 1) * CBW * 4;
     FID_REQUIRE(LDS <= 160 * 1024, "conv3x3_ks: %d bytes of LDS", LDS);
-    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_ks<TH>, LDS));
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_ks<TH, MOSAIC>, LDS));
     const int grid = std::min(a.n_items, ctx->num_cus);
-    hipLaunchKernelGGL((conv3x3_ks<TH>), dim3(grid), dim3(NWT * 64), LDS, ctx->stream, a);
+    hipLaunchKernelGGL((conv3x3_ks<TH, MOSAIC>), dim3(grid), dim3(NWT * 64), LDS, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
 }
 
 }  // namespace
 
+// 7x7 maps (below conv3x3_wr's 12-pixel minimum): four images per 16x16 tile
+bool conv_ks_mosaic(const ConvArgs &a) {
+    return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.H == 7 && a.W == 7 && a.Ho == 7 && a.Wo == 7 && a.Cin_p % 64 == 0 &&
+           a.Cout_p % 16 == 0 && a.Cout_p >= 64 && a.w_rows == a.Cout_p && !(a.flags & (CF_RES_UP2 | CF_ARGMAX | CF_OUT_F32)) && a.nsig == 0 &&
+           (a.res == nullptr || (a.res_H == 7 && a.res_W == 7 && a.res_Cp == a.Cout_p));
+}
+
 bool conv_ks_applicable(const ConvArgs &a) {
     if (getenv("FID_NO_KS")) return false;
-    return conv_wr_applicable(a) && (a.Cin_p / CK) % KS == 0;
+    if ((a.Cin_p / CK) % KS != 0) return false;
+    if (conv_ks_mosaic(a)) return true;
+    return conv_wr_applicable(a);
 }
 
 int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c) {
@@ -386,15 +421,17 @@ int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c) {
     const bool t14 = padded(14) * 16 <= padded(16) * 14;
     auto work = [&](int t) { return (double)padded(t) * 16.0 / t; };
     const bool t10 = work(10) < 0.9 * std::min(work(14), work(16));
-    const int TH = t10 ? 10 : (t14 ? 14 : 16);
+    const bool mosaic = conv_ks_mosaic(c);
+    const int TH = mosaic ? 16 : (t10 ? 10 : (t14 ? 14 : 16));
     KSArgs a{};
     a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
     a.act = c.act; a.flags = c.flags; a.rev = c.rev;
     const int B = c.M / (c.Ho * c.Wo);
+    a.n_img = B;
     a.tiles_x = cdiv(c.W, TH);
     a.tiles_per_img = a.tiles_x * cdiv(c.H, TH);
-    a.n_tiles = B * a.tiles_per_img;
+    a.n_tiles = mosaic ? cdiv(B, 4) : B * a.tiles_per_img;
     a.n_chunks = c.Cin_p / CK;
     a.n_steps_item = a.n_chunks / KS;
     a.n_cblk = cdiv(c.Cout_p, CBW);
@@ -408,6 +445,7 @@ int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c) {
     a.ncls = c.bias ? ((c.flags & CF_BORDER) ? 9 : 1) : 0;
     static const int ablate = getenv("FID_KS_ABLATE") ? atoi(getenv("FID_KS_ABLATE")) : 0;
     a.ablate = ablate;
+    if (mosaic) return ks_launch_t<16, true>(ctx, a);
     if (TH == 10) return ks_launch_t<10>(ctx, a);
     if (TH == 14) return ks_launch_t<14>(ctx, a);
     return ks_launch_t<16>(ctx, a);

@@ -514,6 +514,11 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                         if (rep > 0) tmin = std::min(tmin, ms);
                     }
                     float score = c.ksplit > 1 ? tmin * 1.1f : tmin;
+                    // FID_TUNE_SHARE = s (0 .. 1; plans for two-lane deployments, tools/make_plan.sh): a launch on a fraction f of the CUs scores
+                    // t (1 - s (1 - f)) -- the CUs it leaves free run the other lane's kernels.  Measured on IResNet's 7x7 layers at 64 faces:
+                    // conv_ks MOSAIC (128 workgroups, 38 us) against generation 2 (392 workgroups, 36 us): the step is 1.3 % shorter with MOSAIC.
+                    static const float tune_share = getenv("FID_TUNE_SHARE") ? (float)atof(getenv("FID_TUNE_SHARE")) : 0.f;
+                    if (tune_share > 0.f) score *= 1.f - tune_share * (1.f - conv_plan_cu_share(a, c, ctx->num_cus));
                     if (c.gen == 8) score *= pc2_bias;          // experiments: FID_PC2_BIAS < 1 prefers the two-tile kernel although it is slower alone
                     static const int tune_verbose = getenv("FID_TUNE_LOG") ? atoi(getenv("FID_TUNE_LOG")) : 0;
                     if (tune_verbose >= 2)

@@ -82,6 +82,32 @@ def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3, ran
 
 
+# 7x7 maps (IResNet's last stage): conv_ks packs four images into one 16x16 tile with zero gutters between them (MOSAIC) -- image counts that
+# are / are not multiples of four, a single image, plain / border-class bias, PReLU, residual; against the oracle and against conv_gw (11)
+@pytest.mark.parametrize("gen", [96, 11])
+@pytest.mark.parametrize("chans,batch", [((128, 128), 9), ((64, 192), 3), ((256, 64), 1), ((128, 512), 64), ((64, 64), 4)])
+def test_conv_mosaic_7x7(ctx, monkeypatch, gen, chans, batch):
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    monkeypatch.setenv("FID_FORCE_GEN", str(gen // 10) if gen > 11 else str(gen))
+    if gen > 11:
+        monkeypatch.setenv("FID_FORCE_NS", str(gen % 10))
+    net = stack((7, 7), chans)
+    P = archs.synth_params(net, seed=31)
+    images = np.random.default_rng(33).integers(0, 256, (batch, 7, 7, 3), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    cn.run(images)
+    got = cn.read(net.outputs[0], batch)
+    ran = forced_ran(cn, gen)
+    cn.close()
+    if gen == 96:
+        assert len(ran) >= 3, ran                 # every 3x3 conv of the stack but the 3-channel one (and a1 after 64 -> 192: still even chunk counts)
+    elif not ran:
+        pytest.skip("conv_gw takes no layer of this stack")
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))[net.outputs[0]]
+    ref = np.transpose(ref, (0, 2, 3, 1))
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3, ran
+
+
 # the detector head maps (32 fp32 channels, sigmoid on the class scores) through every family that takes them
 @pytest.mark.parametrize("gen", [0, 1, 2, 5])
 @pytest.mark.parametrize("hw,cin,batch", [((96, 160), 80, 2), ((104, 104), 64, 3)])
