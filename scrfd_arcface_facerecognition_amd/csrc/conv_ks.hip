@@ -54,8 +54,10 @@ struct KSArgs {
 // MOSAIC (TH = 16, 7x7 maps -- IResNet's last stage): a tile is a 2 x 2 mosaic of four images, image (r, c) of the mosaic at tile pixels
 // [8r, 8r + 7) x [8c, 8c + 7); tile row / column 7 and 15 are zero gutters (the zero padding between neighbours: never fetched, computed and
 // dropped), so one 16-pixel matrix column carries two images and an item's 64 x 9 Cin weights serve four images instead of one.
-template <int TH, bool MOSAIC>
+// MODE 2 (the map is one tile high, H = TH -- IResNet's 14x14 stage): patch rows 0 and TH + 1 lie outside the image: zeros, not multiplied.
+template <int TH, int MODE>
 __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
+    constexpr bool MOSAIC = MODE == 1, ONE_ROW = MODE == 2;
     constexpr int TW = TH, PH = TH + 2, NPIX = PH * PW, RH = TH / 2;
     constexpr int P_BLKS = (NPIX * 64 + 1023) / 1024, P_BYTES = P_BLKS * 1024, SLOT = KS * P_BYTES, NS = 2;
     constexpr int N_PIECES = KS * P_BLKS, MAX_P = (N_PIECES + NWT - 1) / NWT;
@@ -178,20 +180,25 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
             const int K = (q % PH) * PW + q / PH;               // lin = K + frow
             pq[set] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + K * 64));
         };
+        // MOSAIC: patch rows 0, 8, 16, 17 (the halo above / below and the two gutters) are zeros and output rows 7, 15 are dropped:
+        // neither read nor multiplied -- 14 of 18 fragments, 38 of 48 products per column
+        constexpr int NR = MOSAIC ? 14 : (ONE_ROW ? TH : PH);
+        auto row_of = [](int j) { return MOSAIC ? (j < 7 ? j + 1 : j + 2) : (ONE_ROW ? j + 1 : j); };
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) {
             if (dx != dx_) continue;
 #pragma unroll
-            for (int r = 0; r < PD; r++) load_p(dx * PH + r, r % (PD + 1));
+            for (int j = 0; j < PD; j++) load_p(dx * PH + row_of(j), j % (PD + 1));
 #pragma unroll
-            for (int r = 0; r < PH; r++) {
-                if (r + PD < PH) load_p(dx * PH + r + PD, (r + PD) % (PD + 1));
+            for (int j = 0; j < NR; j++) {
+                const int r = row_of(j);
+                if (j + PD < NR) load_p(dx * PH + row_of(j + PD), (j + PD) % (PD + 1));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dy = 0; dy < 3; dy++) {
                     const int mi = r - dy;
-                    if (mi < 0 || mi >= TH) continue;
-                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[dy * 3 + dx], pq[r % (PD + 1)], acc[mi], 0, 0, 0);
+                    if (mi < 0 || mi >= TH || (MOSAIC && (mi & 7) == 7)) continue;
+                    acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[dy * 3 + dx], pq[j % (PD + 1)], acc[mi], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -386,14 +393,14 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the surplus loads target registers / LDS of this wave: drain before exit
 }
 
-template <int TH, bool MOSAIC = false>
+template <int TH, int MODE = 0>
 static int ks_launch_t(fid_ctx *ctx, KSArgs &a) {
     constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     const int LDS = 2 * KS * P_BYTES + 1024 + NWT * (TH / 2) * 1024 + (a.ncls + 1) * CBW * 4;
     FID_REQUIRE(LDS <= 160 * 1024, "conv3x3_ks: %d bytes of LDS", LDS);
-    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_ks<TH, MOSAIC>, LDS));
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_ks<TH, MODE>, LDS));
     const int grid = std::min(a.n_items, ctx->num_cus);
-    hipLaunchKernelGGL((conv3x3_ks<TH, MOSAIC>), dim3(grid), dim3(NWT * 64), LDS, ctx->stream, a);
+    hipLaunchKernelGGL((conv3x3_ks<TH, MODE>), dim3(grid), dim3(NWT * 64), LDS, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
 }
@@ -445,9 +452,9 @@ int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c) {
     a.ncls = c.bias ? ((c.flags & CF_BORDER) ? 9 : 1) : 0;
     static const int ablate = getenv("FID_KS_ABLATE") ? atoi(getenv("FID_KS_ABLATE")) : 0;
     a.ablate = ablate;
-    if (mosaic) return ks_launch_t<16, true>(ctx, a);
+    if (mosaic) return ks_launch_t<16, 1>(ctx, a);
     if (TH == 10) return ks_launch_t<10>(ctx, a);
-    if (TH == 14) return ks_launch_t<14>(ctx, a);
+    if (TH == 14) return c.H == 14 ? ks_launch_t<14, 2>(ctx, a) : ks_launch_t<14>(ctx, a);
     return ks_launch_t<16>(ctx, a);
 }
 
