@@ -113,7 +113,7 @@ template <int NI, int STRIDE>
 __global__ void __launch_bounds__(256) stem_conv_mfma(const uint8_t *__restrict__ img, const float *__restrict__ w,
                                                       const float *__restrict__ bias, const float *__restrict__ slope,
                                                       _Float16 *__restrict__ out, int H, int W, int Ho, int Wo, int act,
-                                                      int tiles_x, int tiles_y, int n_tiles) {
+                                                      int tiles_x, int tiles_y, int n_tiles, int ablate) {
     constexpr int CP = NI * 16, TS = 16;                     // output channels (padded), tile edge
     constexpr int PR = (TS - 1) * STRIDE + 3;                // patch rows = patch pixel columns (18 / 33)
     constexpr int ND = (PR * 3 + 1 + 3) / 4;                 // dwords per patch row: 1 byte of lead-in (the window is dword aligned)
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) stem_conv_mfma(const uint8_t *__restrict_
     constexpr int OROWB = CP * 2, CPP = OROWB / 16;          // bytes / 16-byte chunks per output pixel
     __shared__ __attribute__((aligned(16))) _Float16 sIn[PR * RSH + 8];
     __shared__ __attribute__((aligned(16))) _Float16 sWt[CP * 32];
-    __shared__ __attribute__((aligned(16))) char sSt[4 * TS * OROWB];
+    __shared__ __attribute__((aligned(16))) char sSt[4 * 4 * TS * OROWB];         // per wave: its four output rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
 
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) stem_conv_mfma(const uint8_t *__restrict_
             const int iy = iy0 + pr, bx = bx0 + dc * 4;
             const bool rin = (unsigned)iy < (unsigned)H;
             unsigned v4 = 0u;
-            if (rin && bx >= 0 && bx + 4 <= rowbytes) v4 = *(const unsigned *)(base + (size_t)iy * rowbytes + bx);
+            if (rin && bx >= 0 && bx + 4 <= rowbytes && !(ablate & 2)) v4 = *(const unsigned *)(base + (size_t)iy * rowbytes + bx);
             sm_half4 h;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -169,18 +169,22 @@ __global__ void __launch_bounds__(256) stem_conv_mfma(const uint8_t *__restrict_
             *(sm_half4 *)(sIn + pr * RSH + dc * 4) = h;
         }
         __syncthreads();
-        char *sS = sSt + wave * (TS * OROWB);
+        char *sS = sSt + wave * (4 * TS * OROWB);
+        // the wave's four output rows: all K gathers first, then the products, then the staged rows leave as 16-byte stores.  A pixel's
+        // 16-byte chunks are rotated by the pixel index in the staging rows (row pitch = all 32 banks: unrotated, 16 pixels hit one bank).
+        sm_half8 pf[4];
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-            const int orow = wave * 4 + rr;                   // output row of the tile; lane = pixel frow of it
-            const int pbase = (orow * STRIDE) * RSH + 1 + frow * STRIDE * 3;
-            sm_half8 pf;
+            const int pbase = ((wave * 4 + rr) * STRIDE) * RSH + 1 + frow * STRIDE * 3;
 #pragma unroll
-            for (int j = 0; j < 8; j++) pf[j] = sIn[koff[j] >= 0 ? pbase + koff[j] : PR * RSH];
+            for (int j = 0; j < 8; j++) pf[rr][j] = sIn[koff[j] >= 0 ? pbase + koff[j] : PR * RSH];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
 #pragma unroll
             for (int ni = 0; ni < NI; ni++) {
                 sm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], pf[rr], acc, 0, 0, 0);
                 sm_f32x4 v = acc + bv[ni];
                 if (act == ACT_RELU) {
 #pragma unroll
@@ -189,18 +193,17 @@ __global__ void __launch_bounds__(256) stem_conv_mfma(const uint8_t *__restrict_
 #pragma unroll
                     for (int i = 0; i < 4; i++) v[i] = v[i] > 0.f ? v[i] : v[i] * sl[ni][i];
                 }
-                *(sm_half4 *)(sS + frow * OROWB + (ni * 16 + fq * 4) * 2) = __builtin_convertvector(v, sm_half4);
+                const int ch = ni * 2 + (fq >> 1);              // 16-byte chunk of the pixel row
+                *(sm_half4 *)(sS + (rr * TS + frow) * OROWB + (((ch + frow) % CPP) << 4) + (fq & 1) * 8) = __builtin_convertvector(v, sm_half4);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int oy = ty * TS + orow;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int g = lane; g < TS * CPP; g += 64) {
-                const int p = g / CPP, c = g - p * CPP;
-                const sm_u32x4 o = *(const sm_u32x4 *)(sS + p * OROWB + c * 16);
-                const int ox = tx * TS + p;
-                if (oy < Ho && ox < Wo) *(sm_u32x4 *)((char *)out + (((size_t)n * Ho + oy) * Wo + ox) * OROWB + c * 16) = o;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging read back before the next row overwrites it
+        for (int g = lane; g < 4 * TS * CPP; g += 64) {
+            const int p = g / CPP, c = g - p * CPP;             // p = rr * 16 + pixel
+            const sm_u32x4 o = *(const sm_u32x4 *)(sS + p * OROWB + (((c + (p & 15)) % CPP) << 4));
+            const int oy = ty * TS + wave * 4 + (p >> 4), ox = tx * TS + (p & 15);
+            if (oy < Ho && ox < Wo && !(ablate & 1)) *(sm_u32x4 *)((char *)out + (((size_t)n * Ho + oy) * Wo + ox) * OROWB + c * 16) = o;
         }
         __syncthreads();                                      // everyone is done with the patch
     }
@@ -392,8 +395,11 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             const int st = op[W_STRIDE];
             if (!valu && net->in_w % 4 == 0 && (st == 1 || st == 2) && (dst.Cp == 16 || dst.Cp == 32 || dst.Cp == 64)) {
                 const int tx = cdiv(dst.W, 16), ty = cdiv(dst.H, 16), nt = batch * tx * ty;
-                const int g = std::min(nt, ctx->num_cus * 4);
-#define STEMM(NI, ST) hipLaunchKernelGGL((stem_conv_mfma<NI, ST>), dim3(g), dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, op[W_ACT], tx, ty, nt)
+                static const int abl = getenv("FID_STEMM_ABLATE") ? atoi(getenv("FID_STEMM_ABLATE")) : 0;      // timing experiments (wrong results): 1 no stores, 2 no frame loads
+                // workgroups per CU = what fits (64 couts: 146 VGPRs, three waves per SIMD; measured on IResNet's stem at 64 faces: 3 -> 33.9 us, 4 -> 39.8, 6 -> 39.3;
+                // without any load or store 29.4: the K gather and the fp32 epilogue are the time, not the 103 MB of output)
+                const int g = std::min(nt, ctx->num_cus * (dst.Cp == 64 ? 3 : 4));
+#define STEMM(NI, ST) hipLaunchKernelGGL((stem_conv_mfma<NI, ST>), dim3(g), dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, op[W_ACT], tx, ty, nt, abl)
                 if (dst.Cp == 64) { if (st == 1) STEMM(4, 1); else STEMM(4, 2); }
                 else if (dst.Cp == 32) { if (st == 1) STEMM(2, 1); else STEMM(2, 2); }
                 else { if (st == 1) STEMM(1, 1); else STEMM(1, 2); }
