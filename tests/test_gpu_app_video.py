@@ -141,9 +141,13 @@ def test_slot_uploads_overlap_compute():
     serial(); overlapped()                                  # warm-up (autotune, first-touch of the pinned pages)
     ctx.sync()
     ts = min(timed(serial) for _ in range(3))
-    res_s = (pipe.idx.download().copy(), pipe.score.download().copy(), pipe.post.det.download()[:, :1].copy())
+    def results():                                          # (detection rows past a frame's count are unspecified memory: masked out)
+        cnt = pipe.post.counts.download().copy()
+        det = np.where((cnt > 0)[:, None, None], pipe.post.det.download()[:, :1], 0.0)
+        return cnt, pipe.idx.download().copy(), pipe.score.download().copy(), det
+    res_s = results()
     to = min(timed(overlapped) for _ in range(3))
-    res_o = (pipe.idx.download().copy(), pipe.score.download().copy(), pipe.post.det.download()[:, :1].copy())
+    res_o = results()
     for a, b in zip(res_s, res_o):
         assert np.array_equal(a, b)                         # the last step ran on the same buffer contents either way
     print(f"8 steps of 32 x 1080p: serial upload+compute {ts / steps * 1e3:.2f} ms/step, double-buffered {to / steps * 1e3:.2f} ms/step")
