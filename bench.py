@@ -161,7 +161,7 @@ def mfma_roofline(pipe, frames_dev, batch, F):
             "achieved_gbs_algorithmic": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
             "hbm_floor_ms": round(hbm_floor, 4), "mfma_floor_ms": round(mfma_floor, 4), "conv_ms": round(tot_ms, 4),
             "kernel": "MFMA conv kernels of one step (per layer the autotuner's pick among conv_mfma_kernel / conv_mfma_dma_kernel / "
-                      "conv3x3_direct / conv3x3_chunked / conv3x3_pc / conv3x3_pc2 / conv3x3_pcr / conv3x3_wr / conv3x3_s2 / conv_gw / scrfd_stem_fused / stem_conv_mfma)",
+                      "conv3x3_direct / conv3x3_chunked / conv3x3_pc / conv3x3_pc2 / conv3x3_pcr / conv3x3_wr / conv3x3_ks / conv3x3_s2 / conv_gw / conv_bb / scrfd_stem_rows / stem_conv_mfma)",
             "launches": launches, "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2),
             "gflop_per_step": round(tot_flop / 1e9, 1), "algorithmic_gbytes_per_step": round(tot_bytes / 1e9, 3),
             "algorithmic_bytes_per_launch": round(tot_bytes / launches), "per_net": per_net}
