@@ -90,7 +90,8 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident
 // conv_ks.hip (generation 9, ns = 6): conv3x3_wr's one-tile x 64-cout item with the K axis split over two wave groups (few tiles: one item per CU); needs w_alt (kind 2)
 bool conv_ks_applicable(const ConvArgs &a);
 bool conv_ks_mosaic(const ConvArgs &a);      // 7x7 maps: four images share a 16x16 tile
-int conv_ks_launch(fid_ctx *ctx, const ConvArgs &a);
+int conv_ks_launch(fid_ctx *ctx, const ConvArgs &a, int per_wg = 1);   // per_wg = 2: two items per workgroup (plan tile 512)
+int conv_ks_items(const ConvArgs &a);                                   // work items (tiles x 64-cout blocks) of the launch
 
 // conv_s2.hip (generation 10): 3x3 / stride 2 with parity-plane patches and resident weights (64 / 96 input channels); needs w_alt (kind 2)
 bool conv_s2_applicable(const ConvArgs &a);

@@ -394,12 +394,12 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
 }
 
 template <int TH, int MODE = 0>
-static int ks_launch_t(fid_ctx *ctx, KSArgs &a) {
+static int ks_launch_t(fid_ctx *ctx, KSArgs &a, int per_wg) {
     constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     const int LDS = 2 * KS * P_BYTES + 1024 + NWT * (TH / 2) * 1024 + (a.ncls + 1) * CBW * 4;
     FID_REQUIRE(LDS <= 160 * 1024, "conv3x3_ks: %d bytes of LDS", LDS);
     FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_ks<TH, MODE>, LDS));
-    const int grid = std::min(a.n_items, ctx->num_cus);
+    const int grid = per_wg >= 2 ? std::min(cdiv(a.n_items, per_wg), std::max(1, ctx->num_cus / per_wg)) : std::min(a.n_items, ctx->num_cus);   // per_wg = 2: at most half the CUs
     hipLaunchKernelGGL((conv3x3_ks<TH, MODE>), dim3(grid), dim3(NWT * 64), LDS, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
@@ -421,15 +421,28 @@ bool conv_ks_applicable(const ConvArgs &a) {
     return conv_wr_applicable(a);
 }
 
-int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c) {
-    FID_REQUIRE(c.w_alt, "conv3x3_ks needs the fragment-order weights (repack kind 2)");
-    FID_REQUIRE(conv_ks_applicable(c), "conv3x3_ks: layer not applicable");
+static int ks_tile_rows(const ConvArgs &c) {
+    if (conv_ks_mosaic(c)) return 16;
     auto padded = [&](int t) { return (long long)cdiv(c.H, t) * t * cdiv(c.W, t) * t; };
     const bool t14 = padded(14) * 16 <= padded(16) * 14;
     auto work = [&](int t) { return (double)padded(t) * 16.0 / t; };
     const bool t10 = work(10) < 0.9 * std::min(work(14), work(16));
+    return t10 ? 10 : (t14 ? 14 : 16);
+}
+
+int conv_ks_items(const ConvArgs &c) {
+    const int TH = ks_tile_rows(c), B = c.M / (c.Ho * c.Wo);
+    const int tiles = conv_ks_mosaic(c) ? cdiv(B, 4) : B * cdiv(c.W, TH) * cdiv(c.H, TH);
+    return tiles * cdiv(c.Cout_p, CBW);
+}
+
+// per_wg = 2: half the workgroups (at most half the CUs), two or more items each -- longer alone (IResNet-50 stage 3 at 64 faces: 27 vs 20 us per
+// layer) but on half the chip; with two batches in flight the other lane's kernels run on the free half.  The plan decides (tile 512 vs 256).
+int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c, int per_wg) {
+    FID_REQUIRE(c.w_alt, "conv3x3_ks needs the fragment-order weights (repack kind 2)");
+    FID_REQUIRE(conv_ks_applicable(c), "conv3x3_ks: layer not applicable");
     const bool mosaic = conv_ks_mosaic(c);
-    const int TH = mosaic ? 16 : (t10 ? 10 : (t14 ? 14 : 16));
+    const int TH = ks_tile_rows(c);
     KSArgs a{};
     a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
@@ -452,10 +465,10 @@ int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c) {
     a.ncls = c.bias ? ((c.flags & CF_BORDER) ? 9 : 1) : 0;
     static const int ablate = getenv("FID_KS_ABLATE") ? atoi(getenv("FID_KS_ABLATE")) : 0;
     a.ablate = ablate;
-    if (mosaic) return ks_launch_t<16, 1>(ctx, a);
-    if (TH == 10) return ks_launch_t<10>(ctx, a);
-    if (TH == 14) return c.H == 14 ? ks_launch_t<14, 2>(ctx, a) : ks_launch_t<14>(ctx, a);
-    return ks_launch_t<16>(ctx, a);
+    if (mosaic) return ks_launch_t<16, 1>(ctx, a, per_wg);
+    if (TH == 10) return ks_launch_t<10>(ctx, a, per_wg);
+    if (TH == 14) return c.H == 14 ? ks_launch_t<14, 2>(ctx, a, per_wg) : ks_launch_t<14>(ctx, a, per_wg);
+    return ks_launch_t<16>(ctx, a, per_wg);
 }
 
 }  // namespace fid

@@ -31,8 +31,10 @@ def forced_ran(cn, code):
             return p["gen"] == 9 and p["ns"] not in (1, 4, 6) and p["bm"] // 256 == code % 10
         if code == 93:
             return p["gen"] == 9 and p["ns"] == 1
-        if code in (94, 96):
-            return p["gen"] == 9 and p["ns"] == code % 10
+        if code == 94:
+            return p["gen"] == 9 and p["ns"] == 4
+        if code in (96, 97):                                    # conv_ks: one / two items per workgroup (plan tile 256 / 512)
+            return p["gen"] == 9 and p["ns"] == 6 and p["bm"] == (256 if code == 96 else 512)
         return p["gen"] == code
     return [p["name"] for p in cn.plans() if hit(p)]
 
@@ -53,8 +55,9 @@ def stack(hw, chans, res=True):
 # 59 = generation 5 with register-staged producers (FID_PC_RS); 8 = two tiles per weight chunk (the (14, 14) x 5 case: an odd tile count);
 # 91 / 92 = generation 9 (weights in registers; 14-row tiles on the 28 / 14-pixel maps, 10-row tiles on the 20-pixel maps, 16-row tiles elsewhere) with one tile x 64 couts /
 # a pair of tiles x 128 couts per item / (93) one tile x all couts with the layer's weights resident in registers (64 / 96 / 128-cout layers of 64 / 96 channels) / (94) one tile x 64 couts with a four-slot patch ring (pieces three steps ahead); 11 = implicit GEMM with the weights in registers (conv_gw: every conv with >= 96 couts, any kernel size / stride)
-# 96 = generation 9 with the K axis split over two wave groups (conv_ks.hip: one tile x 64 couts per item, 8 waves; layers with an even number of 32-channel chunks)
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 91, 92, 93, 94, 96, 11, 25, 51, 59])
+# 96 = generation 9 with the K axis split over two wave groups (conv_ks.hip: one tile x 64 couts per item, 8 waves; layers with an even number of 32-channel chunks);
+# 97 = the same with two items per workgroup (offered when there are no more items than CUs: half the workgroups, the persistent item loop)
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 91, 92, 93, 94, 96, 97, 11, 25, 51, 59])
 @pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2), ((37, 21), (64, 64), 3),
                                             ((14, 14), (128, 128), 5), ((20, 20), (64, 96), 4), ((20, 20), (224, 224), 3)])
 def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
@@ -62,7 +65,7 @@ def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     if gen == 59:
         monkeypatch.setenv("FID_FORCE_GEN", "5")
         monkeypatch.setenv("FID_PC_RS", "1")
-    elif gen in (25, 51, 91, 92, 93, 94, 96):
+    elif gen in (25, 51, 91, 92, 93, 94, 96, 97):
         monkeypatch.setenv("FID_FORCE_GEN", str(gen // 10))
         monkeypatch.setenv("FID_FORCE_NS", str(gen % 10))
     else:
@@ -84,7 +87,7 @@ def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
 
 # 7x7 maps (IResNet's last stage): conv_ks packs four images into one 16x16 tile with zero gutters between them (MOSAIC) -- image counts that
 # are / are not multiples of four, a single image, plain / border-class bias, PReLU, residual; against the oracle and against conv_gw (11)
-@pytest.mark.parametrize("gen", [96, 11])
+@pytest.mark.parametrize("gen", [96, 97, 11])
 @pytest.mark.parametrize("chans,batch", [((128, 128), 9), ((64, 192), 3), ((256, 64), 1), ((128, 512), 64), ((64, 64), 4)])
 def test_conv_mosaic_7x7(ctx, monkeypatch, gen, chans, batch):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
@@ -99,8 +102,10 @@ def test_conv_mosaic_7x7(ctx, monkeypatch, gen, chans, batch):
     got = cn.read(net.outputs[0], batch)
     ran = forced_ran(cn, gen)
     cn.close()
-    if gen == 96:
-        assert len(ran) >= 3, ran                 # every 3x3 conv of the stack but the 3-channel one (and a1 after 64 -> 192: still even chunk counts)
+    if gen == 97 and not ran:
+        pytest.skip("a single item: nothing to pair")
+    if gen in (96, 97):
+        assert len(ran) >= (3 if gen == 96 else 1), ran                 # every 3x3 conv of the stack but the 3-channel one (and a1 after 64 -> 192: still even chunk counts)
     elif not ran:
         pytest.skip("conv_gw takes no layer of this stack")
     ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))[net.outputs[0]]
