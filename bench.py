@@ -363,6 +363,8 @@ def main():
             else:
                 ln.pipe.run_step(ln.frames_dev, 640, 640, ln.gallery, thresh)
 
+    enqueue_s = []
+
     def timed_region(fn, k):
         """exactly k steps between (barrier + synchronize) pairs; MAX over ranks"""
         if world > 1:
@@ -371,6 +373,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(k):
             fn(i)
+        enqueue_s.append((time.perf_counter() - t0) / k)      # host time to ENQUEUE a step (diagnostic: must stay well below the step time)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -389,8 +392,10 @@ def main():
         step(i)
     torch.cuda.synchronize()
     log("warm-up done")
+    enqueue_s.clear()
     repeats = [timed_region(step, args.steps) for _ in range(max(1, args.repeats))]
     elapsed = float(np.median(repeats))
+    host_enqueue_ms = float(np.median(enqueue_s)) * 1e3
     log(f"timed regions done: {[round(r / args.steps * 1e3, 3) for r in repeats]} ms/step, median {elapsed / args.steps * 1e3:.3f}")
 
     pipe.post.check()
@@ -429,6 +434,7 @@ def main():
                        "parallelism": par + (f", {len(lanes)} batches in flight per GPU on separate HIP streams" if len(lanes) > 1 else "")},
             "repeats": len(repeats), "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in repeats],
             "ms_per_step_min": round(min(repeats) / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
         }
         if not args.no_roofline:
             log("roofline: per-op HIP-event timing")
