@@ -170,6 +170,33 @@ int fid_align_crops(fid_ctx *ctx, const uint8_t *frames_dev, int B, int H, int W
                     const float *kps_dev, const int32_t *counts_dev, int cap, int faces_per_frame,
                     uint8_t *crops_dev, double *M_dev);
 
+/* ---- face gates of the reference's product layer: replaces smart_face_recognition.py:1145-1216
+ * (assess_face_quality), :1218-1297 (get_face_pose_angles / is_side_face), :1299-1399 (analyze_bbox_for_side_face) and the
+ * best-face selection with its four rejections (:1473-1519), for every face of a batch in one launch on the post-process's own
+ * device arrays.  The thresholds are the reference's config.json blocks face_quality / side_face_detection / face_detection. */
+typedef struct fid_gate_config {
+    float size_normalization;
+    float w_detection, w_size, w_blur, w_pose, w_lighting;
+    float ar_extreme_profile, ar_very_strong_profile, ar_strong_profile, ar_very_wide, ar_wide, ar_moderately_wide;
+    float area_extremely_small, area_very_small, area_small, area_very_large, area_large;
+    float compactness_very_low, compactness_low;
+    float confidence_very_low, confidence_low;
+    float edge_position_threshold;
+    int32_t decision_threshold;
+    float yaw_threshold, pitch_threshold;              /* degrees */
+    float confidence_threshold, min_quality_threshold;
+} fid_gate_config;
+enum { FID_GATE_ACCEPT = 0, FID_GATE_NO_FACE = 1, FID_GATE_LOW_CONFIDENCE = 2, FID_GATE_SIDE_FACE = 3, FID_GATE_LOW_QUALITY = 4 };
+/* det [B,cap,5], kps [B,cap,10], counts [B] as fid_scrfd_postprocess writes them; the first min(counts[b], faces_per_frame) slots
+ * of frame b are faces.  pose (optional, may be NULL): [B, faces_per_frame, 2] yaw / pitch in radians, 0 = not available (then the
+ * bbox analysis decides, as in the reference).  Outputs (device): quality [B, faces_per_frame, 5] = overall, blur, pose, lighting,
+ * size (zeros in empty slots); side [B, faces_per_frame] = analyze_bbox_for_side_face's score | is_side_face << 16; best [B, 2] =
+ * index of the FIRST face with the highest det_score (-1: no face) and its verdict (FID_GATE_*), checked in the reference's
+ * order: confidence_threshold, side face, min_quality_threshold. */
+int fid_face_gates(fid_ctx *ctx, const float *det_dev, const float *kps_dev, const int32_t *counts_dev, int B, int cap,
+                   int faces_per_frame, const float *pose_dev, const fid_gate_config *cfg, float *quality_dev,
+                   int32_t *side_dev, int32_t *best_dev);
+
 /* ---- embeddings -> unit fp16 rows: the norm half of reference utils/helpers.py:120-123 ------ */
 int fid_l2_normalize_f16(fid_ctx *ctx, const float *emb_dev, int n, int dim, void *out_f16_dev);
 /* the same for the n = B * faces_per_frame face slots of a batch: slot (b, f) with f >= counts[b] holds no face (reference

@@ -21,6 +21,59 @@ c_f64_p = C.POINTER(C.c_double)
 c_u8_p = C.POINTER(C.c_uint8)
 
 # name -> (restype, argtypes); every symbol include/faceid.h declares
+class GateConfig(C.Structure):
+    """fid_gate_config (include/faceid.h): the reference's config.json blocks face_quality / side_face_detection / face_detection, flattened;
+    the defaults are the reference's own values"""
+    _fields_ = ([("size_normalization", C.c_float)]
+                + [(n, C.c_float) for n in ("w_detection", "w_size", "w_blur", "w_pose", "w_lighting",
+                                            "ar_extreme_profile", "ar_very_strong_profile", "ar_strong_profile", "ar_very_wide", "ar_wide", "ar_moderately_wide",
+                                            "area_extremely_small", "area_very_small", "area_small", "area_very_large", "area_large",
+                                            "compactness_very_low", "compactness_low", "confidence_very_low", "confidence_low", "edge_position_threshold")]
+                + [("decision_threshold", C.c_int32)]
+                + [(n, C.c_float) for n in ("yaw_threshold", "pitch_threshold", "confidence_threshold", "min_quality_threshold")])
+
+    DEFAULTS = dict(size_normalization=10000.0, w_detection=0.4, w_size=0.2, w_blur=0.2, w_pose=0.1, w_lighting=0.1,
+                    ar_extreme_profile=0.2, ar_very_strong_profile=0.3, ar_strong_profile=0.5, ar_very_wide=2.5, ar_wide=2.0, ar_moderately_wide=1.6,
+                    area_extremely_small=1200.0, area_very_small=1800.0, area_small=2500.0, area_very_large=400000.0, area_large=300000.0,
+                    compactness_very_low=0.10, compactness_low=0.6, confidence_very_low=0.15, confidence_low=0.7,
+                    edge_position_threshold=30.0, decision_threshold=4, yaw_threshold=35.0, pitch_threshold=35.0,
+                    confidence_threshold=0.6, min_quality_threshold=0.05)
+
+    def __init__(self, **kw):
+        super().__init__()
+        vals = dict(self.DEFAULTS)
+        unknown = set(kw) - set(vals)
+        if unknown:
+            raise TypeError(f"unknown gate thresholds: {sorted(unknown)}")
+        vals.update(kw)
+        for k, v in vals.items():
+            setattr(self, k, v)
+
+    @classmethod
+    def from_reference_json(cls, cfg: dict) -> "GateConfig":
+        """the reference's config.json (the three blocks the gates read; missing keys keep the defaults)"""
+        q, s, d = cfg.get("face_quality", {}), cfg.get("side_face_detection", {}), cfg.get("face_detection", {})
+        kw = {}
+        if "size_normalization" in q:
+            kw["size_normalization"] = float(q["size_normalization"])
+        for src, dst in (("detection_score", "w_detection"), ("size_score", "w_size"), ("blur_score", "w_blur"), ("pose_score", "w_pose"),
+                         ("lighting_score", "w_lighting")):
+            if src in q.get("weights", {}):
+                kw[dst] = float(q["weights"][src])
+        for block, prefix in (("aspect_ratio_thresholds", "ar_"), ("area_thresholds", "area_"), ("compactness_thresholds", "compactness_"),
+                              ("confidence_thresholds", "confidence_")):
+            for k, v in s.get(block, {}).items():
+                if prefix + k in cls.DEFAULTS:
+                    kw[prefix + k] = float(v)
+        for k in ("edge_position_threshold", "decision_threshold"):
+            if k in s:
+                kw[k] = int(s[k]) if k == "decision_threshold" else float(s[k])
+        for k in ("yaw_threshold", "pitch_threshold", "confidence_threshold", "min_quality_threshold"):
+            if k in d:
+                kw[k] = float(d[k])
+        return cls(**kw)
+
+
 SIGNATURES = {
     "fid_abi_version": (C.c_int, []),
     "fid_last_error": (C.c_char_p, []),
@@ -69,6 +122,8 @@ SIGNATURES = {
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fid_l2_normalize_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fid_l2_normalize_f16_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "fid_face_gates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
     "fid_gallery_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_void_pp]),
     "fid_gallery_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fid_gallery_info": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_int_p]),

@@ -198,3 +198,30 @@ def test_tie_order_rule_of_the_oracle():
     pick = sorted(range(len(det)), key=lambda i: (-float(area[i]), -i))[:3]
     assert len(set(np.round(area[pick], 3))) < 3                      # (the selection did have to break a tie)
     assert np.array_equal(det2, det[pick])
+
+
+def test_face_gates_match_the_reference():
+    """oracle/gates.py against the reference's own assess_face_quality / is_side_face / analyze_bbox_for_side_face
+    (smart_face_recognition.py:1145-1399; tools/gen_golden_gates.py, 600 faces incl. the threshold values): bit for bit"""
+    import json
+    from oracle import gates
+    g = load_golden("gates.npz")
+    cfg = gates.config_from_reference_json(json.loads(bytes(g["config"]).decode()))
+    assert cfg == gates.DEFAULT_CONFIG                      # the defaults ARE the reference's config.json
+    for i in range(len(g["score"])):
+        b = g["bbox"][i]
+        assert np.array_equal(gates.face_quality(b, g["kps"][i], g["score"][i], cfg).astype(np.float64), g["quality"][i]), i
+        flag, score = gates.bbox_side_score(b[2] - b[0], b[3] - b[1], b[1], b[0], g["score"][i], cfg)
+        assert (int(flag), score) == tuple(g["bbox_side"][i]), i
+        assert int(gates.is_side_face(b, g["score"][i], g["pose"][i, 0], g["pose"][i, 1], cfg)) == g["side"][i], i
+    # best-face selection (:1473-1519): first maximum, rejections in the reference's order
+    dets = np.array([[100, 100, 200, 220, 0.7], [300, 80, 420, 230, 0.9], [50, 300, 170, 440, 0.9]], np.float32)
+    kps = np.tile(np.array([[120, 130], [180, 130], [150, 160], [125, 190], [175, 190]], np.float32), (3, 1, 1))
+    assert gates.select_best(dets, kps)[:2] == (1, gates.ACCEPT)
+    assert gates.select_best(dets[:0], kps[:0])[:2] == (-1, gates.NO_FACE)
+    low = dets.copy(); low[:, 4] = (0.3, 0.59, 0.2)
+    assert gates.select_best(low, kps)[:2] == (1, gates.LOW_CONFIDENCE)
+    side = dets.copy(); side[1, :4] = (300, 80, 325, 230)      # ratio 0.17: extreme profile
+    assert gates.select_best(side, kps)[:2] == (1, gates.SIDE_FACE)
+    assert gates.select_best(dets, kps, dict(cfg, min_quality_threshold=0.99))[:2] == (1, gates.LOW_QUALITY)
+    assert gates.select_best(dets, kps, cfg, poses=[(0, 0), (np.radians(50.0), 0), (0, 0)])[:2] == (1, gates.SIDE_FACE)
