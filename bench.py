@@ -116,7 +116,7 @@ def op_bytes(cn, oi, n):
 
 def mfma_roofline(pipe, frames_dev, batch, F):
     """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs and bytes."""
-    from scrfd_arcface_facerecognition_amd.lower import OP_BBLOCK, OP_CONV, OP_DWPW, OP_STEM, OP_STEMFUSED
+    from scrfd_arcface_facerecognition_amd.lower import OP_BBLOCK, OP_CONV, OP_DWPW, OP_MBBLOCK, OP_STEM, OP_STEMFUSED
     tot_ms, tot_flop, tot_bytes, launches, per_net = 0.0, 0.0, 0.0, 0, {}
     for name, cn, imgs, n in (("scrfd_10g", pipe.det, frames_dev, batch), ("arcface_r50", pipe.rec, pipe.crops, batch * F)):
         best = None
@@ -126,7 +126,7 @@ def mfma_roofline(pipe, frames_dev, batch, F):
         t, fl, by, k = 0.0, 0.0, 0.0, 0
         by_name = {nd.name: nd for nd in cn.net.nodes}
         for oi, names in enumerate(cn.low.op_nodes):
-            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED, OP_BBLOCK, OP_DWPW):
+            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK):
                 continue
             macs = sum(node_macs(cn.net, by_name[nm]) for nm in names)
             t += float(best[oi]); fl += 2.0 * macs * n; by += op_bytes(cn, oi, n); k += 1

@@ -87,6 +87,11 @@ bool conv_wr_applicable(const ConvArgs &a);
 bool conv_wr_resident_ok(const ConvArgs &a);
 int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident, int ring);
 
+// mbf_block.hip: MobileFaceNet's bottleneck (1x1 -> depthwise 3x3 / stride 1 | 2 -> 1x1 [+ input]) in one launch, the expanded maps in LDS
+bool mbf_block_applicable(int H, int W, int Cin_p, int Gp, int Cout_p, int stride, bool res);
+int mbf_block_launch(fid_ctx *ctx, const void *x, const void *w1, const float *b1, const float *s1, int act1, const float *dww, const float *dwb,
+                     const float *dws, int dw_act, const void *w2, const float *b2, const float *s2, int act2, bool res, void *out, int B, int H, int W,
+                     int Cin_p, int Gp, int Cout_p, int stride);
 // conv_ks.hip (generation 9, ns = 6): conv3x3_wr's one-tile x 64-cout item with the K axis split over two wave groups (few tiles: one item per CU); needs w_alt (kind 2)
 bool conv_ks_applicable(const ConvArgs &a);
 bool conv_ks_mosaic(const ConvArgs &a);      // 7x7 maps: four images share a 16x16 tile

@@ -4,7 +4,7 @@
 
 namespace fid {
 
-enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6, OP_DWPW = 7 };
+enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6, OP_DWPW = 7, OP_MBBLOCK = 8 };
 
 // int32 word indices inside one op record (FID_OP_WORDS = 32 words)
 enum : int {
@@ -36,6 +36,11 @@ enum : int {
     // OP_DWPW (dwpw.hip; lower.py): the record is the POINTWISE conv's (weights, bias, slopes, activation, residual, W_DST) with W_SRC = the
     // depthwise layer's input and W_STRIDE = its stride; the depthwise layer's fp32 tables and activation: W_F_MACS_* = MACs of both
     W_D_WOFF = 20, W_D_BOFF = 21, W_D_SOFF = 22, W_D_ACT = 23,
+    // OP_MBBLOCK (mbf_block.hip; lower.py): 1x1 -> depthwise 3x3 -> 1x1 [+ input].  The record is the SECOND pointwise conv's (weights [Cout_p][Gp],
+    // bias, slopes, activation, W_DST; W_RES = W_SRC when the block adds its input) with W_SRC = the block input and W_STRIDE = the depthwise
+    // stride; the first pointwise conv's fp16 weights [Gp][Cin_p] / fp32 bias / slopes / activation, the depthwise fp32 tables [9][Gp] / bias /
+    // slopes / activation and the padded expanded width Gp; W_F_MACS_* = the MACs of the three layers
+    W_M_W1 = 20, W_M_B1 = 21, W_M_S1 = 22, W_M_ACT1 = 23, W_M_DW = 24, W_M_DWB = 25, W_M_DWS = 28, W_M_DWACT = 29, W_M_GP = 30,
     // OP_CONV fused with the block's shortcut (lower.py; conv_s2.hip DUAL): second output's tensor id + 1 (0: plain conv), its activation,
     // padded couts of the first output; W_F_MACS_LO then holds the shortcut's MACs per image
     W_X_DST2 = 20, W_X_ACT2 = 21, W_X_COUT1P = 22,

@@ -588,6 +588,18 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                                 dst.ptr, batch, src.H, src.W, dst.H, dst.W, src.Cp, dst.Cp, op[W_STRIDE]));
             break;
         }
+        case OP_MBBLOCK: {
+            const TensorView src = view(net, op[W_SRC], first);
+            FID_REQUIRE(src.dtype == 0 && dst.dtype == 0 && op[W_M_W1] >= 0 && op[W_M_B1] >= 0 && op[W_M_DW] >= 0 && op[W_M_DWB] >= 0 && op[W_WOFF] >= 0 &&
+                        op[W_M_GP] > 0 && (op[W_RES] < 0 || op[W_RES] == op[W_SRC]), "op %d: bad bottleneck record", oi);
+            FID_REQUIRE(dst.H == (src.H - 1) / op[W_STRIDE] + 1 && dst.W == (src.W - 1) / op[W_STRIDE] + 1, "op %d: bottleneck output shape", oi);
+            FID_TRY(mbf_block_launch(ctx, src.ptr, blob + op[W_M_W1], (const float *)(blob + op[W_M_B1]),
+                                     op[W_M_S1] >= 0 ? (const float *)(blob + op[W_M_S1]) : nullptr, op[W_M_ACT1], (const float *)(blob + op[W_M_DW]),
+                                     (const float *)(blob + op[W_M_DWB]), op[W_M_DWS] >= 0 ? (const float *)(blob + op[W_M_DWS]) : nullptr, op[W_M_DWACT],
+                                     blob + op[W_WOFF], bias, slope, op[W_ACT], op[W_RES] >= 0, dst.ptr, batch, src.H, src.W, src.Cp, op[W_M_GP], dst.Cp,
+                                     op[W_STRIDE]));
+            break;
+        }
         case OP_MAXPOOL: {
             const TensorView src = view(net, op[W_SRC], first);
             const long long total = (long long)batch * dst.H * dst.W * (dst.Cp / 8);
@@ -762,14 +774,18 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
                                                      op[W_B_B1] >= 0 && (size_t)op[W_B_B1] + ((op[W_FLAGS] & CF_BORDER) ? 9 : 1) * 256 <= blob_bytes &&
                                                      op[W_B_B2] >= 0 && (size_t)op[W_B_B2] + 256 <= blob_bytes &&
                                                      (op[W_B_ACT1] == ACT_RELU || (op[W_B_ACT1] == ACT_PRELU && op[W_B_S1] >= 0 && (size_t)op[W_B_S1] + 256 <= blob_bytes)))) &&
-                        (op[W_TYPE] != OP_DWPW || (op[W_D_WOFF] >= 0 && op[W_D_BOFF] >= 0 && op[W_WOFF] >= 0 && (op[W_D_ACT] != ACT_PRELU || op[W_D_SOFF] >= 0)));
+                        (op[W_TYPE] != OP_DWPW || (op[W_D_WOFF] >= 0 && op[W_D_BOFF] >= 0 && op[W_WOFF] >= 0 && (op[W_D_ACT] != ACT_PRELU || op[W_D_SOFF] >= 0))) &&
+                        (op[W_TYPE] != OP_MBBLOCK || (op[W_M_W1] >= 0 && op[W_M_B1] >= 0 && op[W_M_DW] >= 0 && op[W_M_DWB] >= 0 && op[W_WOFF] >= 0 && op[W_M_GP] > 0 &&
+                                                      op[W_M_GP] % 32 == 0 && (size_t)op[W_M_DW] + (size_t)9 * op[W_M_GP] * 4 <= blob_bytes &&
+                                                      (op[W_M_ACT1] != ACT_PRELU || op[W_M_S1] >= 0) && (op[W_M_DWACT] != ACT_PRELU || op[W_M_DWS] >= 0) &&
+                                                      (op[W_STRIDE] == 1 || op[W_STRIDE] == 2)));
         if (!ok) {
             delete net;
             set_error("op %d: bad record", oi);
             return FID_E_INVALID;
         }
         const int32_t *dt = &net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS];
-        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK || op[W_TYPE] == OP_DWPW)
+        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK || op[W_TYPE] == OP_DWPW || op[W_TYPE] == OP_MBBLOCK)
             net->macs_per_image += (double)(((unsigned long long)(unsigned)op[W_F_MACS_HI] << 32) | (unsigned)op[W_F_MACS_LO]);
         if (op[W_TYPE] == OP_CONV && op[W_X_DST2] > 0) net->macs_per_image += (double)(unsigned)op[W_F_MACS_LO];   // the fused shortcut's share
         if (op[W_TYPE] == OP_CONV || op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_DWCONV)

@@ -30,7 +30,7 @@ import numpy as np
 from .archs import BN_EPS, Net, infer_shapes
 
 OP_WORDS, TENSOR_WORDS = 32, 8
-OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK, OP_DWPW = 1, 2, 3, 4, 5, 6, 7
+OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK = 1, 2, 3, 4, 5, 6, 7, 8
 ACT = {"none": 0, "relu": 1, "prelu": 2}
 CF_RES_UP2, CF_BORDER, CF_OUT_F32 = 1, 2, 4
 CPAD = 32
@@ -78,6 +78,41 @@ class Lowered:
         self.macs = 0
         self.heads: Dict[str, dict] = {}     # DetHead name -> channel layout of the fused tensor
         self.fused_groups: Dict[str, list] = {}   # fused op name -> graph nodes it covers
+
+
+def _mbf_block(net, i, tensors, tid, shp):
+    """nodes i, i+1, i+2 = pointwise 1x1 -> depthwise 3x3 -> pointwise 1x1 [+ the first one's input] in the shapes csrc/mbf_block.hip takes
+    (mbf_block_applicable): (depthwise node, second pointwise node) or None"""
+    if i + 2 >= len(net.nodes):
+        return None
+    n, d, m = net.nodes[i], net.nodes[i + 1], net.nodes[i + 2]
+    if not (d.kind == "conv" and m.kind == "conv" and n.k == 1 and n.pad == 0 and n.stride == 1 and n.src != "input" and n.res is None
+            and not n.pre_bn and not n.pre_avgpool and not n.res_up2
+            and d.groups == d.cin == d.cout == n.cout and d.groups > 1 and d.k == 3 and d.pad == 1 and d.stride in (1, 2) and d.src == n.name
+            and d.res is None and not d.pre_bn and not d.pre_avgpool
+            and m.groups == 1 and m.k == 1 and m.pad == 0 and m.stride == 1 and m.src == d.name and m.res in (None, n.src)
+            and not m.pre_bn and not m.pre_avgpool and not m.res_up2):
+        return None
+    if n.name in net.outputs or d.name in net.outputs:
+        return None
+    for x in net.nodes:                                   # the two expanded maps feed nothing else
+        if x is not d and (getattr(x, "src", None) == n.name or getattr(x, "res", None) == n.name):
+            return None
+        if x is not m and (getattr(x, "src", None) == d.name or getattr(x, "res", None) == d.name):
+            return None
+    src_t = tensors[tid[n.src]]
+    cin_p, gp, cout_p, H, W = src_t[1], _rup(n.cout, CPAD), _rup(m.cout, CPAD), src_t[2], src_t[3]
+    if src_t[4] != 0 or cin_p % 32 or cin_p > 256 or gp % 32 or cout_p % 16 or cout_p > 256:
+        return None
+    if m.res is not None and (d.stride != 1 or cin_p != cout_p):
+        return None
+    if gp > 512:
+        return None
+    to = 7 if d.stride == 1 else 4                        # LDS: the 9 x 9 region + both expanded maps (csrc/mbf_block.hip mbf_lds_bytes)
+    rup = lambda v: (v + 1023) // 1024 * 1024
+    if rup(81 * (cin_p * 2 + 16)) + rup(81 * (gp * 2 + 16)) + ((to * to + 15) // 16 * 16) * (gp * 2 + 16) > 160 * 1024:
+        return None
+    return d, m
 
 
 def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
@@ -339,6 +374,47 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             op_nodes.append([n.name, m.name])
             out.fused_groups[m.name] = [n.name, m.name]
             skip.add(ni_ + 1)
+        elif (n.kind == "conv" and n.groups == 1 and not os.environ.get("FID_NO_MBF_FUSE") and _mbf_block(net, ni_, tensors, tid, shp) is not None):
+            # MobileFaceNet's bottleneck: 1x1 (cin -> G, act) -> depthwise 3x3 / stride 1 | 2 (G, act) -> 1x1 (G -> cout) [+ block input] as ONE launch
+            # (csrc/mbf_block.hip): both expanded maps stay in LDS.  The record is the second pointwise conv's; words 20-25, 28-30 hold the first
+            # pointwise conv's and the depthwise layer's tables (csrc/net.h W_M_*), 26 / 27 the MACs of the three layers.
+            d, m = _mbf_block(net, ni_, tensors, tid, shp)
+            src_t = tensors[tid[n.src]]
+            cin_p, gp, cout_p = src_t[1], _rup(n.cout, CPAD), _rup(m.cout, CPAD)
+            W1, b1 = folded(n)
+            w1_off = blob.add(pack_weights(W1, cin_p, gp))[0]
+            b1_off = blob.add(padded(b1, gp))[0]
+            s1_off = blob.add(padded(P[n.wname + ".prelu"], gp))[0] if n.act == "prelu" else -1
+            Wdw = P[d.wname + ".weight"].astype(np.float64)[:, 0]      # [G, 3, 3]
+            bdw = P[d.wname + ".bias"].astype(np.float64) if d.bias else np.zeros(d.cout)
+            if d.post_bn:
+                a2, b2 = _bn_affine(P, d.wname + ".post_bn")
+                Wdw = Wdw * a2[:, None, None]
+                bdw = bdw * a2 + b2
+            Wd = np.zeros((9, gp), dtype=np.float32)
+            Wd[:, :d.cout] = Wdw.reshape(d.cout, 9).T
+            dw_off = blob.add(Wd)[0]
+            dwb_off = blob.add(padded(bdw, gp))[0]
+            dws_off = blob.add(padded(P[d.wname + ".prelu"], gp))[0] if d.act == "prelu" else -1
+            W2, b2 = folded(m)
+            w2_off, w2_bytes = blob.add(pack_weights(W2, gp, cout_p))
+            b2_off = blob.add(padded(b2, cout_p)[None, :])[0]
+            s2_off = blob.add(padded(P[m.wname + ".prelu"], cout_p))[0] if m.act == "prelu" else -1
+            _, ho, wo = shp[m.name]
+            dst = new_tensor(m.name, m.cout, ho, wo)
+            emit(m.name, type=OP_MBBLOCK, src=tid[n.src], dst=dst, res=tid[m.res] if m.res else -1, kh=3, kw=3, stride=d.stride, pad=1, cin=n.cin,
+                 cout=m.cout, act=ACT[m.act], flags=0, woff=w2_off, wbytes=w2_bytes, boff=b2_off, soff=s2_off, wrows=cout_p)
+            r = ops[-1]
+            r[20], r[21], r[22], r[23], r[24], r[25], r[28], r[29], r[30] = w1_off, b1_off, s1_off, ACT[n.act], dw_off, dwb_off, dws_off, ACT[d.act], gp
+            _, h1, w1_ = shp[n.name]
+            macs = h1 * w1_ * n.cout * n.cin + ho * wo * d.cout * 9 + ho * wo * m.cout * m.cin
+            r[26], r[27] = macs & 0xFFFFFFFF, macs >> 32
+            if r[26] >= 2 ** 31:
+                r[26] -= 2 ** 32
+            op_nodes[-1] = [n.name, d.name, m.name]
+            out.fused_groups[m.name] = [n.name, d.name, m.name]
+            skip.add(ni_ + 1)
+            skip.add(ni_ + 2)
         elif n.kind == "conv" and n.groups == 1:
             cin, cout = n.cin, n.cout
             _, ho, wo = shp[n.name]

@@ -280,3 +280,39 @@ def test_fused_depthwise_pointwise(ctx, monkeypatch, fuse, hw, groups, cout, str
     ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["pw"], (0, 2, 3, 1))
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3
+
+
+# MobileFaceNet's bottleneck (1x1 -> depthwise 3x3 -> 1x1 [+ block input]) as ONE launch with both expanded maps in LDS (csrc/mbf_block.hip):
+# fused and unfused lowering against the oracle -- the net's five block shapes (tiled 28x28 / 56x56 maps with a halo, whole 14x14 / 7x7 maps with
+# 256 input channels, stride 2 with 512 expanded channels), odd maps with partial tiles, a single image, more than 128 couts (two items per tile),
+# ReLU / no activation variants
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("hw,cin,g,cout,stride,res,acts,batch", [
+    ((28, 28), 128, 128, 128, 1, True, ("prelu", "prelu", "none"), 3), ((56, 56), 128, 128, 128, 2, False, ("prelu", "prelu", "none"), 2),
+    ((28, 28), 128, 256, 256, 2, False, ("prelu", "prelu", "none"), 2), ((14, 14), 256, 256, 256, 1, True, ("prelu", "prelu", "none"), 5),
+    ((14, 14), 256, 512, 256, 2, False, ("prelu", "prelu", "none"), 3), ((7, 7), 256, 256, 256, 1, True, ("prelu", "prelu", "none"), 4),
+    ((30, 22), 64, 96, 64, 1, True, ("relu", "relu", "relu"), 1), ((37, 21), 64, 128, 96, 2, False, ("none", "relu", "prelu"), 2),
+    ((12, 9), 224, 160, 208, 1, False, ("prelu", "none", "none"), 3)])
+def test_fused_bottleneck(ctx, monkeypatch, fuse, hw, cin, g, cout, stride, res, acts, batch):
+    from scrfd_arcface_facerecognition_amd import lower
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    if not fuse:
+        monkeypatch.setenv("FID_NO_MBF_FUSE", "1")
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 64, act="relu"))
+    net.add(Conv("x", "s", 64, cin, k=1, pad=0, act="prelu"))
+    net.add(Conv("b.pw1", "x", cin, g, k=1, pad=0, act=acts[0]))
+    net.add(Conv("b.dw", "b.pw1", g, g, stride=stride, groups=g, act=acts[1]))
+    net.add(Conv("b.pw2", "b.dw", g, cout, k=1, pad=0, act=acts[2], res="x" if res else None))
+    net.outputs = ["b.pw2"]
+    P = archs.synth_params(net, seed=51)
+    low = lower.lower(net, P)
+    assert (sum(int(r[0]) == 8 for r in low.ops) == 1) == fuse and (sum(int(r[0]) == 4 for r in low.ops) == 0) == fuse
+    images = np.random.default_rng(12).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    cn.run(images)
+    got = cn.read("b.pw2", batch)
+    cn.close()
+    ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["b.pw2"], (0, 2, 3, 1))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3
