@@ -1,7 +1,7 @@
 // MobileFaceNet's bottleneck in ONE launch:  pointwise 1x1 (Cin -> G, act) -> depthwise 3x3 / stride 1 | 2 (G, act) -> pointwise 1x1 (G -> Cout)
 // [+ block input] (reference models/arcface.py:51 runs w600k_mbf inside session.run; main.py:19-30 defaults to this recogniser; BASELINE
-// configs[4]).  At 32 faces the net was 51 launches of 6-12 us (profiles/r03: each a load -> compute -> store chain of a few dependent memory
-// round trips, ~6 us even when empty of work): 48 of them are the three layers of 16 such blocks.  Here the two expanded maps never leave LDS
+// configs[4]).  At 32 faces the net was 50 launches of 6-12 us (profiles/r03: each a load -> compute -> store chain of a few dependent memory
+// round trips, ~6 us even when empty of work): 45 of them are the three layers of 15 such blocks.  Here the two expanded maps never leave LDS
 // and EVERY global load of a block is requested up front or a slice ahead; between them there are only LDS, MFMA and VALU stages.
 //
 //   item    = a tile of To x To output pixels of one image (To = 7 at stride 1, 4 at stride 2) x a block of 128 couts; its input region -- the
