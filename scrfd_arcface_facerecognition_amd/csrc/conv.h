@@ -110,7 +110,7 @@ int conv_gw_launch(fid_ctx *ctx, const ConvArgs &a, int bm, int bn);
 // conv_bb.hip: a residual BasicBlock on 64 channels (conv3x3 + ReLU, conv3x3, + input, activation) in one launch; w1 / w2 are repack
 // kind 2 images packed by lower.py
 int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1, int ncls1, int act1, const float *s1, const void *w2, const float *b2,
-                   void *out, int B, int H, int W, int act2, int rev);
+                   void *out, int B, int H, int W, int act2, int rev, int Cp = 64);
 
 // dwpw.hip: depthwise 3x3 (stride 1 | 2, pad 1) + the pointwise 1x1 conv that consumes it, one launch (MobileFaceNet bottlenecks, SCRFD-500M)
 bool dwpw_applicable(int Gp, int Cout_p);

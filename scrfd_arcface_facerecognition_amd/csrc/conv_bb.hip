@@ -310,11 +310,226 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the surplus pieces target this workgroup's LDS: drain before exit
 }
 
+
+// ======================================================================================================================================
+// The same block on 32 stored channels (SCRFD-2.5G layer1: 24 -> 32 padded, three blocks at 160x160): ONE 32-channel chunk, two cout fragments.
+// FOUR waves = (cout fragment cw = 0..1) x (row group rg = 0..1): the 64-channel kernel's row split (conv1 rows 8 rg .. 8 rg + 7, conv2 rows
+// 7 rg .. 7 rg + 6) with half the cout fragments.  Both filter banks of a wave are 2 x 9 fragments = 72 VGPRs; LDS = two 21 KB patch buffers +
+// 16 KB intermediate tile + 14 KB staging = 74 KB: TWO workgroups per CU, whose barriers and epilogues interleave (eight waves in one workgroup
+// with four rows each: 57.6 us per block at 160x160x32 frames, 35 us of it with no conv at all -- one lock-step group per CU hides nothing).
+// Plain bias + ReLU after conv1 only (SCRFD's form).  Same operation order per wave and item as above: [top: ST_I32 stores of the tile staged
+// by the item before] [conv1's three tap columns: one piece each of the NEXT item's patch].
+// ======================================================================================================================================
+constexpr int NW32 = 4;
+constexpr int MAX_P32 = (P_BLKS + NW32 - 1) / NW32;               // 6 pieces per wave: two per tap column of conv1
+constexpr int MID32 = MW * MW * 64;                               // 16 KB
+constexpr int ROWB32 = 64, CPX32 = 4;
+constexpr int ST_I32 = (TO * 16 * CPX32 + NW32 * 64 - 1) / (NW32 * 64);    // 4
+constexpr int STG32 = TO * 16 * ROWB32;
+constexpr int OFF32_SPARE = 2 * P_BYTES, OFF32_MID = OFF32_SPARE + 1024, OFF32_STG = OFF32_MID + MID32 + 512, LDS32 = OFF32_STG + STG32;
+static_assert(MAX_P32 == 6 && LDS32 <= 80 * 1024, "two workgroups per CU");
+
+__global__ void __launch_bounds__(NW32 * 64, 2) conv_bb32(const BBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 1, rg = wave >> 1;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int bid = xcd_major_id(blockIdx.x, gridDim.x);
+    const int my_items = bid < a.n_tiles ? (a.n_tiles - 1 - bid) / gridDim.x + 1 : 0;
+    if (my_items == 0) return;
+    auto decode_tile = [&](int item, int &n, int &ty, int &tx) {
+        if (a.rev) item = a.n_tiles - 1 - item;
+        n = fastdiv(item, a.d_tpi);
+        const int r = item - n * a.tiles_per_img;
+        ty = fastdiv(r, a.d_tx); tx = r - ty * a.tiles_x;
+    };
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.io_bytes, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, a.io_bytes, 0x00020000);
+
+    int p_pk[MAX_P32];                                          // py | px << 8 | channel offset (halfs) << 16; py = 255: nothing to fetch
+#pragma unroll
+    for (int k = 0; k < MAX_P32; k++) {
+        const int j = wave + NW32 * k;
+        const int row = j * 16 + (lane >> 2);
+        int py = row / PW;
+        const int px = row - py * PW;
+        if (row >= NPIX || j >= P_BLKS) py = 255;
+        p_pk[k] = py | (px << 8) | ((((lane & 3) ^ swz64(row)) * 8) << 16);
+    }
+    auto issue_piece = [&](int k, int n, int ty, int tx, bool live, int buf) {
+        const int y0 = ty * TO - 2, x0 = tx * TO - 2;
+        const int j = wave + NW32 * k;
+        int pk = p_pk[k];
+        asm volatile("" : "+v"(pk));
+        const int py = pk & 255, iy = y0 + py, ix = x0 + ((pk >> 8) & 255);
+        const bool in = live && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 8);
+        const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * 32 + (pk >> 16)) * 2) : OOB;
+        char *d = j < P_BLKS ? smem + buf * P_BYTES + j * 1024 : smem + OFF32_SPARE;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)d, 16, vo, 0, 0, 0);
+    };
+    {
+        int n, ty, tx;
+        decode_tile(bid, n, ty, tx);
+#pragma unroll
+        for (int k = 0; k < MAX_P32; k++) issue_piece(k, n, ty, tx, true, 0);
+    }
+    half8 w1[9], w2[9];                                         // [dy * 3 + dx]
+    {
+        const char *p1 = (const char *)a.w1 + cw * 9216 + lane * 16, *p2 = (const char *)a.w2 + cw * 9216 + lane * 16;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                w1[dy * 3 + dx] = *(const half8 *)(p1 + dx * 3072 + dy * 1024);
+                w2[dy * 3 + dx] = *(const half8 *)(p2 + dx * 3072 + dy * 1024);
+            }
+    }
+    const f32x4 bias1 = *(const f32x4 *)(a.b1 + cw * 16 + fq * 4), bias2 = *(const f32x4 *)(a.b2 + cw * 16 + fq * 4);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 9; i++) asm volatile("" : "+v"(w1[i]), "+v"(w2[i]));
+
+    int pbase[2][4];
+#pragma unroll
+    for (int par = 0; par < 2; par++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) pbase[par][c] = frow * 64 + ((fq ^ ((((frow + par) >> 1) + c) & 3)) << 4);
+
+    f32x4 acc[8];
+    constexpr int PD = BB_PD;
+    // one conv: ROWS output rows of this wave from ROWS + 2 fragment rows x 3 tap columns (one flattened sequence, read PD rows ahead across the columns)
+    auto conv_phase = [&](int base_off, auto rows_tag, auto pw_tag, const half8 *wv, auto &&col_hook) {
+        constexpr int ROWS = decltype(rows_tag)::value, PWV = decltype(pw_tag)::value, PH = ROWS + 2, NQ = 3 * PH;
+        int pb[2][4];
+#pragma unroll
+        for (int par = 0; par < 2; par++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                pb[par][c] = pbase[par][c] + base_off;
+                asm volatile("" : "+v"(pb[par][c]));
+            }
+        half8 pq[PD + 1];
+        auto load_p = [&](int q) {                              // q = dx * PH + fragment row
+            const int dx = q / PH, r = q - dx * PH;
+            const int K = r * PWV + dx;
+            pq[q % (PD + 1)] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + K * 64));
+        };
+#pragma unroll
+        for (int q = 0; q < PD; q++) load_p(q);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int dx = q / PH, r = q - dx * PH;
+            if (r == 0) col_hook(dx);
+            if (q + PD < NQ) load_p(q + PD);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const int mi = r - dy;
+                if (mi < 0 || mi >= ROWS) continue;
+                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[dy * 3 + dx], pq[q % (PD + 1)], acc[mi], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using std::integral_constant;
+    // write-out of the tile staged by the item before: 16-byte slot g = i * 256 + thread = (pixel g / 4, chunk g % 4); 64 pixels = 4 tile rows per round
+    auto write_out = [&](int pn, int pty, int ptx) {
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int q0 = t2 >> 2, c = t2 & 3;
+        const int pr0 = q0 >> 4, pc = q0 & 15;
+        const int oy0 = pty * TO, ox = ptx * TO + pc;
+        const bool okc = pn >= 0 && pc < TO && ox < a.W && !(a.ablate & 4);
+        const char *lsrc = smem + OFF32_STG + q0 * ROWB32 + (((c + pc) % CPX32) << 4);
+        const unsigned g0 = (unsigned)((((pn * a.H + oy0 + pr0) * a.W + ox) * 32 + c * 8) * 2);
+        const unsigned rstride = (unsigned)(a.W * 32 * 2);
+#pragma unroll
+        for (int i = 0; i < ST_I32; i++) {
+            const int row = 4 * i + pr0;
+            const bool ok = okc && row < TO && oy0 + row < a.H;
+            const u32x4 v = *(const u32x4 *)(lsrc + (row < TO ? i * (64 * ROWB32) : 0));
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, ok ? g0 + (unsigned)(4 * i) * rstride : OOB, 0, 0);
+        }
+    };
+    auto no_hook = [](int) {};
+
+    int item = bid, pn = -1, pty = 0, ptx = 0;
+    for (int it = 0; it < my_items; it++, item += gridDim.x) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();                                          // everybody's pieces; the tile of the item before is staged; its patch buffer is free
+        write_out(pn, pty, ptx);
+        int n, ty, tx, nn, nty, ntx;
+        decode_tile(item, n, ty, tx);
+        const bool nlive = it + 1 < my_items;
+        decode_tile(nlive ? item + gridDim.x : 0, nn, nty, ntx);
+        auto fetch_hook = [&](int pass) { issue_piece(2 * pass, nn, nty, ntx, nlive, buf ^ 1); issue_piece(2 * pass + 1, nn, nty, ntx, nlive, buf ^ 1); };   // two pieces of the next patch per tap column
+
+        // ================= A: conv1 on the 16x16 region (rows 8 rg .. 8 rg + 7 here) =================
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(a.ablate & 1)) {
+            conv_phase(buf * P_BYTES + rg * (8 * PW * 64), integral_constant<int, 8>{}, integral_constant<int, PW>{}, w1, fetch_hook);
+        } else {
+#pragma unroll
+            for (int k = 0; k < MAX_P32; k++) issue_piece(k, nn, nty, ntx, nlive, buf ^ 1);
+        }
+        {
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int fr = lo & 15, q4 = lo >> 4;
+            const int gx = tx * TO - 1 + fr, gy0 = ty * TO - 1 + rg * 8;
+            const bool xin = (unsigned)gx < (unsigned)a.W;
+            char *mp = smem + OFF32_MID + (rg * 8 * MW + fr) * 64 + (((cw * 2 + (q4 >> 1)) ^ swz64(fr)) << 4) + (q4 & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                half4 h = __builtin_elementwise_max(__builtin_convertvector(acc[i] + bias1, half4), half4{0, 0, 0, 0});
+                if (!(xin && (unsigned)(gy0 + i) < (unsigned)a.H)) h = half4{0, 0, 0, 0};      // outside the image: conv2's zero padding
+                *(half4 *)(mp + i * (MW * 64)) = h;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();                                          // the intermediate tile is complete
+
+        // ================= B: conv2 on the 14x14 tile (rows 7 rg .. 7 rg + 6 here) =================
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(a.ablate & 2)) conv_phase(OFF32_MID + rg * (7 * MW * 64), integral_constant<int, 7>{}, integral_constant<int, MW>{}, w2, no_hook);
+        {
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int fr = lo & 15, q4 = lo >> 4;
+            const int g0 = cw * 2 + (q4 >> 1);
+            const char *xp = smem + buf * P_BYTES + (q4 & 1) * 8;
+            char *sp = smem + OFF32_STG + fr * ROWB32 + (((cw * 2 + (q4 >> 1) + fr) % CPX32) << 4) + (q4 & 1) * 8;
+            half4 rs[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const int r = rg * 7 + i, lin = (r + 2) * PW + fr + 2;
+                rs[i] = *(const half4 *)(xp + lin * 64 + ((g0 ^ swz64(lin)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const int r = rg * 7 + i;
+                f32x4 v = acc[i] + bias2 + __builtin_convertvector(rs[i], f32x4);
+                half4 h = __builtin_convertvector(v, half4);
+                if (a.act2 == ACT_RELU) h = __builtin_elementwise_max(h, half4{0, 0, 0, 0});
+                *(half4 *)(sp + r * (16 * ROWB32)) = h;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pn = n; pty = ty; ptx = tx;
+    }
+    raw_barrier();
+    write_out(pn, pty, ptx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
-// x [B, H, W, 64] fp16 -> out [B, H, W, 64]; w1 / w2: repack kind 2 images (147 456 B each), b1 fp32 [ncls1][64], b2 fp32 [64], s1 fp32 [64] or NULL
+// x [B, H, W, Cp] fp16 -> out [B, H, W, Cp], Cp = 64 | 32 stored channels; w1 / w2: repack kind 2 images (147 456 B | 73 728 B each), b1 fp32 [ncls1][64], b2 fp32 [64], s1 fp32 [64] or NULL
 int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1, int ncls1, int act1, const float *s1, const void *w2, const float *b2,
-                   void *out, int B, int H, int W, int act2, int rev) {
+                   void *out, int B, int H, int W, int act2, int rev, int Cp) {
     FID_REQUIRE(in && w1 && w2 && b1 && b2 && out && B > 0 && H >= 3 && W >= 3, "conv_bb: bad arguments");
     FID_REQUIRE((act2 == ACT_RELU || act2 == ACT_NONE) && (act1 == ACT_RELU || (act1 == ACT_PRELU && s1)) && (ncls1 == 1 || ncls1 == 9), "conv_bb: activations %d / %d, %d bias rows", act1, act2, ncls1);
     BBArgs a{};
@@ -325,11 +540,18 @@ int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1
     a.tiles_per_img = a.tiles_x * cdiv(H, TO);
     a.n_tiles = B * a.tiles_per_img;
     a.d_tpi = fastdiv_make(a.tiles_per_img); a.d_tx = fastdiv_make(a.tiles_x);
-    const size_t bytes = (size_t)B * H * W * 64 * 2;
+    FID_REQUIRE(Cp == 64 || (Cp == 32 && ncls1 == 1 && act1 == ACT_RELU), "conv_bb: %d stored channels (%d bias rows, activation %d)", Cp, ncls1, act1);
+    const size_t bytes = (size_t)B * H * W * Cp * 2;
     FID_REQUIRE(bytes <= OOB, "conv_bb: tensor larger than 2 GiB");
     a.io_bytes = (unsigned)bytes;
     static const int ablate = getenv("FID_BB_ABLATE") ? atoi(getenv("FID_BB_ABLATE")) : 0;
     a.ablate = ablate;
+    if (Cp == 32) {                                             // four waves, two workgroups per CU
+        FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb32, LDS32));
+        hipLaunchKernelGGL(conv_bb32, dim3(std::min(a.n_tiles, 2 * ctx->num_cus)), dim3(NW32 * 64), LDS32, ctx->stream, a);
+        FID_HIP(hipGetLastError());
+        return FID_OK;
+    }
     const int grid = std::min(a.n_tiles, ctx->num_cus);
     if (ncls1 == 9 || act1 == ACT_PRELU) {
         FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb<true>, LDS_BYTES));

@@ -566,11 +566,11 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
         }
         case OP_BBLOCK: {
             const TensorView src = view(net, op[W_SRC], first);
-            FID_REQUIRE(src.Cp == 64 && dst.Cp == 64 && src.H == dst.H && src.W == dst.W && src.dtype == 0 && dst.dtype == 0, "op %d: bad fused block record", oi);
+            FID_REQUIRE((src.Cp == 64 || src.Cp == 32) && dst.Cp == src.Cp && src.H == dst.H && src.W == dst.W && src.dtype == 0 && dst.dtype == 0, "op %d: bad fused block record", oi);
             const int rev = net->alternate && !net->tdir[op[W_SRC]];
             FID_TRY(conv_bb_launch(ctx, src.ptr, blob + op[W_B_W1], (const float *)(blob + op[W_B_B1]), (op[W_FLAGS] & CF_BORDER) ? 9 : 1, op[W_B_ACT1],
                                    op[W_B_S1] >= 0 ? (const float *)(blob + op[W_B_S1]) : nullptr, blob + op[W_B_W2], (const float *)(blob + op[W_B_B2]), dst.ptr,
-                                   batch, dst.H, dst.W, op[W_ACT], rev));
+                                   batch, dst.H, dst.W, op[W_ACT], rev, src.Cp));
             net->tdir[op[W_DST]] = (char)rev;
             break;
         }
@@ -770,7 +770,7 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
                         op[W_RES] >= -1 && op[W_RES] < n_tensors && op[W_WOFF] >= -1 &&
                         (op[W_WOFF] < 0 || (size_t)op[W_WOFF] + (size_t)op[W_WBYTES] <= blob_bytes) &&
                         (op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_STEMFUSED) == (op[W_SRC] == -1) &&
-                        (op[W_TYPE] != OP_BBLOCK || (op[W_B_W1] >= 0 && op[W_B_W2] >= 0 && (size_t)std::max(op[W_B_W1], op[W_B_W2]) + 147456 <= blob_bytes &&
+                        (op[W_TYPE] != OP_BBLOCK || (op[W_B_W1] >= 0 && op[W_B_W2] >= 0 && (size_t)std::max(op[W_B_W1], op[W_B_W2]) + 73728 <= blob_bytes &&      // (a kind-2 image: 73 728 B per 32-channel chunk)
                                                      op[W_B_B1] >= 0 && (size_t)op[W_B_B1] + ((op[W_FLAGS] & CF_BORDER) ? 9 : 1) * 256 <= blob_bytes &&
                                                      op[W_B_B2] >= 0 && (size_t)op[W_B_B2] + 256 <= blob_bytes &&
                                                      (op[W_B_ACT1] == ACT_RELU || (op[W_B_ACT1] == ACT_PRELU && op[W_B_S1] >= 0 && (size_t)op[W_B_S1] + 256 <= blob_bytes)))) &&

@@ -335,8 +335,9 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
               and nxt.groups == 1 and n.k == 3 and nxt.k == 3 and n.stride == 1 and nxt.stride == 1 and n.pad == 1 and nxt.pad == 1
               and n.act in ("relu", "prelu") and nxt.act in ("relu", "none") and n.res is None and nxt.res == n.src and nxt.src == n.name
               and not n.res_up2 and not nxt.res_up2 and not nxt.pre_bn and not n.pre_avgpool and not nxt.pre_avgpool
-              and n.src != "input" and tensors[tid[n.src]][1] == 64 and tensors[tid[n.src]][4] == 0 and _rup(n.cout, CPAD) == 64
-              and _rup(nxt.cout, CPAD) == 64 and n.name not in net.outputs and tensors[tid[n.src]][2] >= 3 and tensors[tid[n.src]][3] >= 3
+              and n.src != "input" and tensors[tid[n.src]][1] in (32, 64) and tensors[tid[n.src]][4] == 0 and _rup(n.cout, CPAD) == tensors[tid[n.src]][1]
+              and _rup(nxt.cout, CPAD) == tensors[tid[n.src]][1] and (tensors[tid[n.src]][1] == 64 or (n.act == "relu" and not n.pre_bn))
+              and n.name not in net.outputs and tensors[tid[n.src]][2] >= 3 and tensors[tid[n.src]][3] >= 3
               and not any(getattr(x, "src", None) == n.name or getattr(x, "res", None) == n.name for x in net.nodes if x is not nxt)):
             # A residual BasicBlock on 64 stored channels (SCRFD-10G layer1): conv1 + ReLU -> conv2 -> + block input -> activation as ONE
             # launch (csrc/conv_bb.hip): conv1's output only feeds conv2, so it is never materialised.  Both filter banks go into the blob
@@ -348,11 +349,12 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             W1, bt1, _, _ = fold_conv(n, (src_t[2], src_t[3]))
             W2, bt2, _, _ = fold_conv(m, (src_t[2], src_t[3]))
             assert bt2.shape[0] == 1
-            b1t = np.zeros((bt1.shape[0], 64), dtype=np.float32)
+            cpb = src_t[1]                                            # 64 stored channels, or 32 (conv_bb32: SCRFD-2.5G layer1)
+            b1t = np.zeros((bt1.shape[0], cpb), dtype=np.float32)
             b1t[:, :n.cout] = bt1
-            offs = [blob.add(repack_kind2(pack_weights(W1, 64, 64)))[0], blob.add(b1t)[0],
-                    blob.add(repack_kind2(pack_weights(W2, 64, 64)))[0], blob.add(padded(bt2[0], 64))[0]]
-            s1_off = blob.add(padded(P[n.wname + ".prelu"], 64))[0] if n.act == "prelu" else -1
+            offs = [blob.add(repack_kind2(pack_weights(W1, cpb, cpb)))[0], blob.add(b1t)[0],
+                    blob.add(repack_kind2(pack_weights(W2, cpb, cpb)))[0], blob.add(padded(bt2[0], cpb))[0]]
+            s1_off = blob.add(padded(P[n.wname + ".prelu"], cpb))[0] if n.act == "prelu" else -1
             _, ho, wo = shp[m.name]
             dst = new_tensor(m.name, m.cout, ho, wo)
             rec = [0] * OP_WORDS

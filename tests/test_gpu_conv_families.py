@@ -210,7 +210,9 @@ def test_fused_shortcut_stride2(ctx, monkeypatch, fuse, hw, planes, batch):
 @pytest.mark.parametrize("fuse", [True, False])
 # ("ir": IResNet's form -- BN - conv - BN - PReLU - conv - BN, + input -- conv1 then carries 9 border-class bias rows and PReLU slopes)
 @pytest.mark.parametrize("hw,planes,batch,act2", [((56, 84), 56, 3, "relu"), ((37, 45), 64, 2, "relu"), ((12, 20), 56, 5, "none"), ((160, 160), 56, 1, "relu"),
-                                                  ((29, 16), 40, 4, "relu"), ((56, 56), 64, 3, "ir"), ((23, 31), 64, 2, "ir"), ((14, 14), 64, 5, "ir")])
+                                                  ((29, 16), 40, 4, "relu"), ((56, 56), 64, 3, "ir"), ((23, 31), 64, 2, "ir"), ((14, 14), 64, 5, "ir"),
+                                                  # 32 stored channels (conv_bb32: SCRFD-2.5G layer1): four row groups, rows 14 / 15 of the last one dropped
+                                                  ((56, 84), 24, 3, "relu"), ((37, 45), 32, 2, "none"), ((160, 160), 24, 1, "relu"), ((12, 20), 16, 5, "relu")])
 def test_fused_basic_block(ctx, monkeypatch, fuse, hw, planes, batch, act2):
     from scrfd_arcface_facerecognition_amd import lower
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
