@@ -125,23 +125,36 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
         for (int j0 = 0; j0 * NWV + wave < frags1 && !(a.ablate & 1); j0 += 2) {
             if (j0 > 0) load_w1(j0);                            // (layers with more than 256 expanded channels: the next pair, one more trip)
 #pragma unroll 1
-            for (int pf = 0; pf < NPF; pf++) {                  // (not unrolled: six iterations' fragment reads in flight at once spilled the resident weights)
-                const int px = pf * 16 + frow, pxc = px < RPX ? px : 0;
-                const char *xr = sX + pxc * a.xs_pitch + fq * 16;
-                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            for (int pf = 0; pf < NPF; pf += 2) {               // (two pixel fragments per iteration = four independent accumulator chains; not unrolled
+                                                                //  further: six iterations' fragment reads in flight at once spilled the resident weights)
+                f32x4 acc[2][2];
 #pragma unroll
-                for (int k = 0; k < KS1; k++) {
-                    const half8 bf = *(const half8 *)(xr + k * 64);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[0][k], bf, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[1][k], bf, acc1, 0, 0, 0);
+                for (int h = 0; h < 2; h++) acc[h][0] = acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const char *xr[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int px = (pf + h) * 16 + frow;
+                    xr[h] = sX + (px < RPX ? px : 0) * a.xs_pitch + fq * 16;
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int fr = wave + NWV * (j0 + u);
-                    f32x4 v = (u ? acc1 : acc0) + b1v[u];
-                    if (a.act1 == ACT_PRELU) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + s1v[u] * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
-                    else if (a.act1 == ACT_RELU) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
-                    if (px < RPX && fr < frags1) *(half4 *)(sE + px * a.e_pitch + (fr * 16 + fq * 4) * 2) = __builtin_convertvector(v, half4);
+                for (int k = 0; k < KS1; k++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const half8 bf = *(const half8 *)(xr[h] + k * 64);
+                        acc[h][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[0][k], bf, acc[h][0], 0, 0, 0);
+                        acc[h][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[1][k], bf, acc[h][1], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int px = (pf + h) * 16 + frow;
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int fr = wave + NWV * (j0 + u);
+                        f32x4 v = acc[h][u] + b1v[u];
+                        if (a.act1 == ACT_PRELU) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + s1v[u] * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                        else if (a.act1 == ACT_RELU) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                        if (px < RPX && fr < frags1) *(half4 *)(sE + px * a.e_pitch + (fr * 16 + fq * 4) * 2) = __builtin_convertvector(v, half4);
+                    }
                 }
             }
         }
@@ -163,8 +176,7 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
                     for (int dx = 0; dx < 3; dx++) {
                         if ((unsigned)(iy0 + dy) >= (unsigned)a.H || (unsigned)(ix0 + dx) >= (unsigned)a.W) continue;       // (a skipped tap, as in dwconv_nhwc)
                         const half4 e = *(const half4 *)(e0 + (dy * RW + dx) * a.e_pitch);
-#pragma unroll
-                        for (int jj = 0; jj < 4; jj++) acc[jj] = fmaf((float)e[jj], dwv[dy * 3 + dx][jj], acc[jj]);
+                        acc = __builtin_elementwise_fma(__builtin_convertvector(e, f32x4), dwv[dy * 3 + dx], acc);     // (four fused multiply-adds, packed two by two: the same bits as fmaf per channel)
                     }
                 half4 o;
 #pragma unroll
