@@ -26,7 +26,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NWV = 8, NTH = NWV * 64;
-constexpr int RW = 9, RPX = RW * RW, NPF = (RPX + 15) / 16;      // the input region of an item: 9 x 9 pixels (6 pixel fragments) at either stride
+// the input region of an item: RW x RW pixels, RW = (To - 1) stride + 3 = 9 (7 x 7 outputs at stride 1, 4 x 4 at stride 2) or 15 (7 x 7 outputs at
+// stride 2 where both expanded maps of 225 pixels fit LDS: the 56 -> 28 block, a quarter of the workgroups)
 constexpr int MAXOF = 4;                                         // pixel fragments of an output tile (7 x 7 = 49 pixels at stride 1, 4 x 4 at stride 2)
 
 struct MBArgs {
@@ -42,13 +43,15 @@ struct MBArgs {
     int act1, dw_act, act2, res;
     int To;                    // output tile edge: 7 (stride 1) | 4 (stride 2); the region is ((To - 1) stride + 3)^2 = 9 x 9 input pixels
     int tiles_x, tiles_per_img, n_items, ncb;      // ncb = cout blocks of 128 per tile
+    int cb_in_wg;              // 1: a workgroup walks the cout blocks of its tile itself (items = tiles); 0: one item per (tile, cout block)
     int xs_pitch, e_pitch, off_e, off_d;
     int ablate;                // FID_MB_ABLATE timing experiments (wrong results): 1 no stage A, 2 no stage B, 4 no stage C, 16 no region fetch
 };
 
-// KS1 = Cin_p / 32 (K-steps of pw1).
-template <int KS1>
+// KS1 = Cin_p / 32 (K-steps of pw1); RW = the region's edge (9 | 15).
+template <int KS1, int RW>
 __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
+    constexpr int RPX = RW * RW, NPF = (RPX + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
     const int chunks = a.Cin_p >> 3;                            // 16-byte chunks per pixel of x
 
     for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
-        const int cb = item % a.ncb, it = item / a.ncb;
+        const int cb0 = a.cb_in_wg ? 0 : item % a.ncb, it = a.cb_in_wg ? item : item / a.ncb;      // cout block(s) of this item
         const int n = it / a.tiles_per_img, t = it - n * a.tiles_per_img;
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
         const int oy0 = ty * a.To, ox0 = tx * a.To;
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
             }
         };
         half8 w2f[8];
-        const int fr2 = cb * NWV + wave, fr2c = fr2 < frags2 ? fr2 : 0;
+        int fr2 = cb0 * NWV + wave, fr2c = fr2 < frags2 ? fr2 : 0;
         auto load_w2 = [&](int k0) {                            // K-steps k0 .. k0 + 7 of my pw2 fragment
             const _Float16 *p = a.w2 + (size_t)(fr2c * 16 + frow) * a.Gp + fq * 8;
 #pragma unroll
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
         for (int j0 = 0; j0 * NWV + wave < frags1 && !(a.ablate & 1); j0 += 2) {
             if (j0 > 0) load_w1(j0);                            // (layers with more than 256 expanded channels: the next pair, one more trip)
 #pragma unroll 1
-            for (int pf = 0; pf < NPF; pf += 2) {               // (two pixel fragments per iteration = four independent accumulator chains; not unrolled
+            for (int pf = 0; pf < NPF; pf += 2) {               // (two pixel fragments per iteration; a fragment past the region clamps its reads and skips its stores = four independent accumulator chains; not unrolled
                                                                 //  further: six iterations' fragment reads in flight at once spilled the resident weights)
                 f32x4 acc[2][2];
 #pragma unroll
@@ -160,8 +163,8 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
         }
         // pw2's operands are requested now (not at the top: 40 more live registers through stage A spilled): they travel during stage B
         load_w2(0);
-        const f32x4 b2v = a.b2 ? *(const f32x4 *)(a.b2 + fr2c * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 s2v = a.act2 == ACT_PRELU ? *(const f32x4 *)(a.s2 + fr2c * 16 + fq * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+        f32x4 b2v = a.b2 ? *(const f32x4 *)(a.b2 + fr2c * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 s2v = a.act2 == ACT_PRELU ? *(const f32x4 *)(a.s2 + fr2c * 16 + fq * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
         __syncthreads();                                        // E is complete
         // ======== B: depthwise 3x3 on E -> D (fp32 fmaf chain in dwconv_nhwc's order, taps outside the image skipped) ========
         if (cg < cgs && pl < npl && !(a.ablate & 2)) {
@@ -190,7 +193,14 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
             }
         }
         __syncthreads();                                        // D is complete
-        // ======== C: pw2 for my cout fragment, K = the expanded channels ========
+        // ======== C: pw2 for my cout fragment, K = the expanded channels (cb_in_wg: for my fragment of every cout block in turn) ========
+        for (int cb = cb0; cb < (a.cb_in_wg ? a.ncb : cb0 + 1); cb++) {
+        if (cb > cb0) {                                         // the next block's operands: one more trip (half the workgroups instead)
+            fr2 = cb * NWV + wave; fr2c = fr2 < frags2 ? fr2 : 0;
+            load_w2(0);
+            b2v = a.b2 ? *(const f32x4 *)(a.b2 + fr2c * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s2v = a.act2 == ACT_PRELU ? *(const f32x4 *)(a.s2 + fr2c * 16 + fq * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+        }
         f32x4 acc2[MAXOF];
 #pragma unroll
         for (int p = 0; p < MAXOF; p++) acc2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -224,6 +234,7 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
                 *(half4 *)(a.out + ((size_t)(n * a.Ho + oy0 + oyl) * a.Wo + ox0 + oxl) * a.Cout_p + co) = __builtin_convertvector(v, half4);
             }
         }
+        }
         __syncthreads();                                        // the residual reads of sX are done before the next item's region overwrites it
     }
 }
@@ -231,10 +242,15 @@ __global__ void __launch_bounds__(NTH) mbf_block(const MBArgs a) {
 }  // namespace
 
 // region + both expanded maps (lower.py's _mbf_block mirrors this)
-static int mbf_lds_bytes(int Cin_p, int Gp, int stride) {
-    const int To = stride == 1 ? 7 : 4, drows = ((To * To + 15) / 16) * 16;
-    const int xs = ((RPX * (Cin_p * 2 + 16) + 1023) / 1024) * 1024, e = ((RPX * (Gp * 2 + 16) + 1023) / 1024) * 1024;
+static int mbf_lds_bytes(int Cin_p, int Gp, int To, int stride) {
+    const int rw = (To - 1) * stride + 3, rpx = rw * rw, drows = ((To * To + 15) / 16) * 16;
+    const int xs = ((rpx * (Cin_p * 2 + 16) + 1023) / 1024) * 1024, e = ((rpx * (Gp * 2 + 16) + 1023) / 1024) * 1024;
     return xs + e + drows * (Gp * 2 + 16);
+}
+// output tile edge: 7 at stride 1; at stride 2 7 when the 15 x 15 region fits LDS, else 4
+static int mbf_tile(int Cin_p, int Gp, int stride) {
+    if (stride == 1) return 7;
+    return mbf_lds_bytes(Cin_p, Gp, 7, 2) <= 160 * 1024 ? 7 : 4;
 }
 
 bool mbf_block_applicable(int H, int W, int Cin_p, int Gp, int Cout_p, int stride, bool res) {
@@ -243,7 +259,7 @@ bool mbf_block_applicable(int H, int W, int Cin_p, int Gp, int Cout_p, int strid
     if (Cin_p % 32 || Gp % 32 || Cout_p % 16 || Cin_p > 256 || Cin_p < 32 || Cout_p > 256 || Gp > 512 || Gp < 32) return false;
     if (res && (stride != 1 || Cin_p != Cout_p)) return false;
     if ((Gp / 4) > NTH) return false;                            // stage B: at least one pixel lane per 4-channel group
-    return H >= 1 && W >= 1 && mbf_lds_bytes(Cin_p, Gp, stride) <= 160 * 1024;
+    return H >= 1 && W >= 1 && mbf_lds_bytes(Cin_p, Gp, mbf_tile(Cin_p, Gp, stride), stride) <= 160 * 1024;
 }
 
 int mbf_block_launch(fid_ctx *ctx, const void *x, const void *w1, const float *b1, const float *s1, int act1, const float *dww, const float *dwb,
@@ -255,22 +271,27 @@ int mbf_block_launch(fid_ctx *ctx, const void *x, const void *w1, const float *b
     a.b2 = b2; a.s2 = s2; a.out = (_Float16 *)out;
     a.H = H; a.W = W; a.stride = stride; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1;
     a.Cin_p = Cin_p; a.Gp = Gp; a.Cout_p = Cout_p; a.act1 = act1; a.dw_act = dw_act; a.act2 = act2; a.res = res;
-    a.To = stride == 1 ? 7 : 4;
+    a.To = mbf_tile(Cin_p, Gp, stride);
+    const int rw = (a.To - 1) * stride + 3, rpx = rw * rw;
     a.tiles_x = cdiv(a.Wo, a.To);
     a.tiles_per_img = a.tiles_x * cdiv(a.Ho, a.To);
     a.ncb = cdiv(Cout_p / 16, NWV);
-    a.n_items = B * a.tiles_per_img * a.ncb;
+    // cout blocks as separate items recompute the expanded maps per block: worth it only while the items still fit one round of workgroups
+    a.cb_in_wg = a.ncb > 1 && B * a.tiles_per_img * a.ncb > ctx->num_cus;
+    a.n_items = B * a.tiles_per_img * (a.cb_in_wg ? 1 : a.ncb);
     a.xs_pitch = Cin_p * 2 + 16;
     a.e_pitch = Gp * 2 + 16;
-    a.off_e = ((RPX * a.xs_pitch + 1023) / 1024) * 1024;
-    a.off_d = a.off_e + ((RPX * a.e_pitch + 1023) / 1024) * 1024;
-    const int lds = mbf_lds_bytes(Cin_p, Gp, stride);
+    a.off_e = ((rpx * a.xs_pitch + 1023) / 1024) * 1024;
+    a.off_d = a.off_e + ((rpx * a.e_pitch + 1023) / 1024) * 1024;
+    const int lds = mbf_lds_bytes(Cin_p, Gp, a.To, stride);
     const int ks1 = Cin_p / 32;
     static const int ablate = getenv("FID_MB_ABLATE") ? atoi(getenv("FID_MB_ABLATE")) : 0;
     a.ablate = ablate;
     const int grid = std::min(a.n_items, ctx->num_cus * std::max(1, (160 * 1024) / lds));
-#define MB_GO(K) do { FID_TRY(ensure_dyn_lds(ctx, (const void *)mbf_block<K>, lds)); \
-                      hipLaunchKernelGGL((mbf_block<K>), dim3(grid), dim3(NTH), lds, ctx->stream, a); } while (0)
+#define MB_GO(K) do { if (rw == 9) { FID_TRY(ensure_dyn_lds(ctx, (const void *)mbf_block<K, 9>, lds)); \
+                                         hipLaunchKernelGGL((mbf_block<K, 9>), dim3(grid), dim3(NTH), lds, ctx->stream, a); } \
+                      else { FID_TRY(ensure_dyn_lds(ctx, (const void *)mbf_block<K, 15>, lds)); \
+                             hipLaunchKernelGGL((mbf_block<K, 15>), dim3(grid), dim3(NTH), lds, ctx->stream, a); } } while (0)
     switch (ks1) { case 1: MB_GO(1); break; case 2: MB_GO(2); break; case 3: MB_GO(3); break; case 4: MB_GO(4); break;
                    case 5: MB_GO(5); break; case 6: MB_GO(6); break; case 7: MB_GO(7); break; default: MB_GO(8); break; }
 #undef MB_GO

@@ -108,8 +108,8 @@ def _mbf_block(net, i, tensors, tid, shp):
         return None
     if gp > 512:
         return None
-    to = 7 if d.stride == 1 else 4                        # LDS: the 9 x 9 region + both expanded maps (csrc/mbf_block.hip mbf_lds_bytes)
-    rup = lambda v: (v + 1023) // 1024 * 1024
+    to = 7 if d.stride == 1 else 4                        # LDS: the 9 x 9 region + both expanded maps (csrc/mbf_block.hip mbf_lds_bytes; the kernel
+    rup = lambda v: (v + 1023) // 1024 * 1024            #  takes 7 x 7 tiles at stride 2 as well when their 15 x 15 region fits)
     if rup(81 * (cin_p * 2 + 16)) + rup(81 * (gp * 2 + 16)) + ((to * to + 15) // 16 * 16) * (gp * 2 + 16) > 160 * 1024:
         return None
     return d, m

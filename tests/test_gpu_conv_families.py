@@ -295,7 +295,9 @@ def test_fused_depthwise_pointwise(ctx, monkeypatch, fuse, hw, groups, cout, str
     ((28, 28), 128, 256, 256, 2, False, ("prelu", "prelu", "none"), 2), ((14, 14), 256, 256, 256, 1, True, ("prelu", "prelu", "none"), 5),
     ((14, 14), 256, 512, 256, 2, False, ("prelu", "prelu", "none"), 3), ((7, 7), 256, 256, 256, 1, True, ("prelu", "prelu", "none"), 4),
     ((30, 22), 64, 96, 64, 1, True, ("relu", "relu", "relu"), 1), ((37, 21), 64, 128, 96, 2, False, ("none", "relu", "prelu"), 2),
-    ((12, 9), 224, 160, 208, 1, False, ("prelu", "none", "none"), 3)])
+    ((12, 9), 224, 160, 208, 1, False, ("prelu", "none", "none"), 3),
+    # more (tile, cout block) items than CUs: a workgroup walks both cout blocks of its tile itself
+    ((28, 28), 128, 256, 256, 2, False, ("prelu", "prelu", "none"), 9), ((21, 30), 96, 128, 160, 1, False, ("prelu", "prelu", "none"), 12)])
 def test_fused_bottleneck(ctx, monkeypatch, fuse, hw, cin, g, cout, stride, res, acts, batch):
     from scrfd_arcface_facerecognition_amd import lower
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
