@@ -393,14 +393,15 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             dim3 grid((unsigned)cdiv64(total, 64));
             static const bool valu = getenv("FID_STEM_VALU") != nullptr;   // the VALU kernel stays for comparison
             const int st = op[W_STRIDE];
-            if (!valu && net->in_w % 4 == 0 && (st == 1 || st == 2) && (dst.Cp == 16 || dst.Cp == 32 || dst.Cp == 64)) {
+            if (!valu && net->in_w % 4 == 0 && (st == 1 || st == 2) && (dst.Cp == 16 || dst.Cp == 32 || dst.Cp == 64 || dst.Cp == 128)) {
                 const int tx = cdiv(dst.W, 16), ty = cdiv(dst.H, 16), nt = batch * tx * ty;
                 static const int abl = getenv("FID_STEMM_ABLATE") ? atoi(getenv("FID_STEMM_ABLATE")) : 0;      // timing experiments (wrong results): 1 no stores, 2 no frame loads
                 // workgroups per CU = what fits (64 couts: 146 VGPRs, three waves per SIMD; measured on IResNet's stem at 64 faces: 3 -> 33.9 us, 4 -> 39.8, 6 -> 39.3;
                 // without any load or store 29.4: the K gather and the fp32 epilogue are the time, not the 103 MB of output)
-                const int g = std::min(nt, ctx->num_cus * (dst.Cp == 64 ? 3 : 4));
+                const int g = std::min(nt, ctx->num_cus * (dst.Cp == 128 ? 2 : (dst.Cp == 64 ? 3 : 4)));
 #define STEMM(NI, ST) hipLaunchKernelGGL((stem_conv_mfma<NI, ST>), dim3(g), dim3(256), 0, ctx->stream, images, w, bias, slope, (_Float16 *)dst.ptr, net->in_h, net->in_w, dst.H, dst.W, op[W_ACT], tx, ty, nt, abl)
-                if (dst.Cp == 64) { if (st == 1) STEMM(4, 1); else STEMM(4, 2); }
+                if (dst.Cp == 128) { if (st == 1) STEMM(8, 1); else STEMM(8, 2); }            // (MobileFaceNet's first conv: 3 -> 128 channels, stride 2)
+                else if (dst.Cp == 64) { if (st == 1) STEMM(4, 1); else STEMM(4, 2); }
                 else if (dst.Cp == 32) { if (st == 1) STEMM(2, 1); else STEMM(2, 2); }
                 else { if (st == 1) STEMM(1, 1); else STEMM(1, 2); }
 #undef STEMM
