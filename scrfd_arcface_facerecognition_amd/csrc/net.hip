@@ -279,6 +279,84 @@ __global__ void __launch_bounds__(256) dwconv_nhwc(const _Float16 *__restrict__ 
     *(half8 *)(out + (size_t)pix * Cp + cg * 8) = o;
 }
 
+// ---- depthwise 3x3 / stride 1 / pad 1 with the input tile in LDS ("LDS halo tiles, half8 reads"): a workgroup takes a tile of
+// 14 rows x 16 columns x 64 channels; its haloed 16 x 18 input patch (37 KB) is fetched once (16-byte loads, every input byte once per tile
+// instead of nine times through L1), thread = (8-channel group, column, row half) walks its 7 output rows with a three-row window in
+// registers (three 16-byte LDS reads per output instead of nine global ones).  fp32 fmaf chain in dwconv_nhwc's (dy, dx) order from the
+// bias, taps outside the image SKIPPED: bit-identical to dwconv_nhwc.  MobileFaceNet's conv2_dw (128 x 56 x 56, 32 faces): 41 -> see DESIGN.
+constexpr int DW_TR = 14, DW_TC = 16, DW_PR = DW_TR + 2, DW_PC = DW_TC + 2;
+__global__ void __launch_bounds__(256) dwconv3x3_lds(const _Float16 *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                                                     const float *__restrict__ slope, _Float16 *__restrict__ out, int H, int W, int Cp, int act,
+                                                     int tiles_x, int tiles_y, int cblks) {
+    __shared__ __attribute__((aligned(16))) char sP[DW_PR * DW_PC * 128];
+    const int tid = threadIdx.x;
+    int item = blockIdx.x;
+    const int cb = item % cblks; item /= cblks;
+    const int tx = item % tiles_x; item /= tiles_x;
+    const int ty = item % tiles_y, n = item / tiles_y;
+    const int y0 = ty * DW_TR - 1, x0 = tx * DW_TC - 1, c0 = cb * 64;
+    // patch: 16 x 18 pixels x 8 chunks of 16 bytes; pixels outside the image are never read back (their taps are skipped): left as they are
+    for (int i = tid; i < DW_PR * DW_PC * 8; i += 256) {
+        const int p = i >> 3, c = i & 7;
+        const int py = p / DW_PC, px = p - py * DW_PC;
+        const int iy = y0 + py, ix = x0 + px;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            *(uint4 *)(sP + p * 128 + c * 16) = *(const uint4 *)(in + ((size_t)(n * H + iy) * W + ix) * Cp + c0 + c * 8);
+    }
+    const int cg = tid & 7, col = (tid >> 3) & 15, rh = tid >> 7;          // 8-channel group, tile column, row half (7 rows each)
+    float wv[9][8], bv[8], sv[8];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) wv[t][i] = w[(size_t)t * Cp + c0 + cg * 8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        bv[i] = bias[c0 + cg * 8 + i];
+        sv[i] = act == ACT_PRELU ? slope[c0 + cg * 8 + i] : 1.f;
+    }
+    __syncthreads();
+    const int ox = tx * DW_TC + col;
+    const bool okc[3] = {(unsigned)(ox - 1) < (unsigned)W, ox < W, (unsigned)(ox + 1) < (unsigned)W};
+    if (ox >= W) return;
+    half8 win[3][3];                                            // [patch row (mod 3)][dx]
+    const char *base = sP + col * 128 + cg * 16;
+    auto load_row = [&](int pr, int slot) {
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) win[slot][dx] = *(const half8 *)(base + (pr * DW_PC + dx) * 128);
+    };
+    const int r0 = rh * (DW_TR / 2);
+    load_row(r0, 0); load_row(r0 + 1, 1);
+#pragma unroll
+    for (int r = 0; r < DW_TR / 2; r++) {
+        load_row(r0 + r + 2, (r + 2) % 3);
+        const int oy = ty * DW_TR + r0 + r;
+        if (oy >= H) break;
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = bv[i];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            if ((unsigned)(oy - 1 + dy) >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                if (!okc[dx]) continue;
+                const half8 v = win[(r + dy) % 3][dx];
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc[i] = fmaf((float)v[i], wv[dy * 3 + dx][i], acc[i]);
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float a = acc[i];
+            if (act == ACT_RELU) a = fmaxf(a, 0.f);
+            else if (act == ACT_PRELU) a = a > 0.f ? a : a * sv[i];
+            o[i] = (_Float16)a;
+        }
+        *(half8 *)(out + ((size_t)(n * H + oy) * W + ox) * Cp + c0 + cg * 8) = o;
+    }
+}
+
 // reads `n16` 16-byte words (tuning only: brings a layer's input back into L2 / the Infinity Cache after the cache flush, where the
 // producing layer would have left it)
 __global__ void __launch_bounds__(256) touch_kernel(const uint4 *__restrict__ p, size_t n16, unsigned *sink) {
@@ -611,6 +689,16 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
         case OP_DWCONV: {
             const TensorView src = view(net, op[W_SRC], first);
             const long long total = (long long)batch * dst.H * dst.W * (dst.Cp / 8);
+            static const bool dw_global = getenv("FID_DW_GLOBAL") != nullptr;      // A/B: the kernel without the LDS tile everywhere
+            // launches with enough pixels take the LDS-tiled kernel (below ~50 k pixels a launch is latency-bound either way: SCRFD-500M on ONE frame measured
+            // 1.4 % slower with it, on 32 frames 1.3 % faster; MobileFaceNet's 56 x 56 x 128 layer at 32 faces 41 -> 27.6 us)
+            if (!dw_global && op[W_KH] == 3 && op[W_KW] == 3 && op[W_STRIDE] == 1 && op[W_PAD] == 1 && dst.Cp % 64 == 0 && src.H >= 12 && src.W >= 12 &&
+                (long long)batch * src.H * src.W >= 50000) {
+                const int tx = cdiv(src.W, DW_TC), ty = cdiv(src.H, DW_TR), cbs = dst.Cp / 64;
+                hipLaunchKernelGGL(dwconv3x3_lds, dim3((unsigned)(batch * ty * tx * cbs)), dim3(256), 0, ctx->stream, (const _Float16 *)src.ptr,
+                                   (const float *)(blob + op[W_WOFF]), bias, slope, (_Float16 *)dst.ptr, src.H, src.W, dst.Cp, op[W_ACT], tx, ty, cbs);
+                break;
+            }
             hipLaunchKernelGGL(dwconv_nhwc, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, (const _Float16 *)src.ptr,
                                (const float *)(blob + op[W_WOFF]), bias, slope, (_Float16 *)dst.ptr, src.H, src.W, dst.H, dst.W,
                                dst.Cp, op[W_KH], op[W_STRIDE], op[W_PAD], op[W_ACT], total);
