@@ -143,6 +143,58 @@ __global__ void __launch_bounds__(256) letterbox_kernel(const uint8_t *frames, i
     }
 }
 
+// The same arithmetic, FOUR consecutive output pixels per thread (in_w % 4 == 0): a source pixel is one unaligned 4-byte load instead of three
+// 1-byte loads and the 12 output bytes leave as three aligned dwords -- 16 + 3 memory instructions per 4 pixels instead of 48 + 12 (32 frames of
+// 1080p -> 640x640: cfg 5 step 1.548 -> 1.535 ms).  `src_bytes` = bytes of the whole frame batch: the last pixel of the batch is read bytewise.
+__global__ void __launch_bounds__(256) letterbox_kernel4(const uint8_t *frames, int H, int W, uint8_t *out, int in_h, int in_w, int new_h, int new_w,
+                                                         double scale_x, double scale_y, size_t src_bytes) {
+    const int b = blockIdx.z;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= in_w) return;
+    unsigned *o = (unsigned *)(out + (((size_t)b * in_h + y) * in_w + x4) * 3);
+    unsigned char px[12];
+    const size_t fbase = (size_t)b * H * W * 3;
+    auto fetch = [&](size_t off) -> unsigned {                  // the 3 bytes of a source pixel (byte 3 of the word is ignored)
+        if (off + 4 <= src_bytes) {
+            unsigned v;
+            __builtin_memcpy(&v, frames + off, 4);
+            return v;
+        }
+        return (unsigned)frames[off] | ((unsigned)frames[off + 1] << 8) | ((unsigned)frames[off + 2] << 16);
+    };
+    auto coeff = [](int d, double scale, int n, int &s0, int &s1, int &a0, int &a1) {
+        float f = (float)(((double)d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= n - 1) { s = n - 1; f = 0.f; }
+        s0 = s; s1 = min(s + 1, n - 1);
+        a1 = (int)rintf(__fmul_rn(f, 2048.f));
+        a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+    };
+    int sy0 = 0, sy1 = 0, b0 = 0, b1 = 0;
+    if (y < new_h) coeff(y, scale_y, H, sy0, sy1, b0, b1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x4 + i;
+        if (x >= new_w || y >= new_h) { px[3 * i] = px[3 * i + 1] = px[3 * i + 2] = 0; continue; }
+        int sx0, sx1, a0, a1;
+        coeff(x, scale_x, W, sx0, sx1, a0, a1);
+        const unsigned p00 = fetch(fbase + ((size_t)sy0 * W + sx0) * 3), p01 = fetch(fbase + ((size_t)sy0 * W + sx1) * 3);
+        const unsigned p10 = fetch(fbase + ((size_t)sy1 * W + sx0) * 3), p11 = fetch(fbase + ((size_t)sy1 * W + sx1) * 3);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int T0 = (int)((p00 >> (8 * c)) & 255u) * a0 + (int)((p01 >> (8 * c)) & 255u) * a1;
+            const int T1 = (int)((p10 >> (8 * c)) & 255u) * a0 + (int)((p11 >> (8 * c)) & 255u) * a1;
+            const int v = (((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2;
+            px[3 * i + c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        o[j] = (unsigned)px[4 * j] | ((unsigned)px[4 * j + 1] << 8) | ((unsigned)px[4 * j + 2] << 16) | ((unsigned)px[4 * j + 3] << 24);
+}
+
 }  // namespace
 
 extern "C" {
@@ -174,6 +226,14 @@ int fid_letterbox(fid_ctx *ctx, const uint8_t *frames_dev, int B, int H, int W, 
     std::lock_guard<std::mutex> lk(ctx->mu);
     dim3 grid(fid::cdiv(in_w, 256), in_h, B);
     const int area2x = (W == 2 * new_w && H == 2 * new_h) ? 1 : 0;
+    static const bool lb_bytes = getenv("FID_LETTERBOX_BYTES") != nullptr;      // A/B: the one-pixel-per-thread kernel everywhere
+    if (!lb_bytes && !area2x && !(new_w == W && new_h == H) && in_w % 4 == 0 && ((size_t)out_dev & 3) == 0) {
+        dim3 grid4(fid::cdiv(in_w / 4, 256), in_h, B);
+        hipLaunchKernelGGL(letterbox_kernel4, grid4, dim3(256), 0, ctx->stream, frames_dev, H, W, out_dev, in_h, in_w, new_h, new_w,
+                           (double)W / (double)new_w, (double)H / (double)new_h, (size_t)B * H * W * 3);
+        FID_HIP(hipGetLastError());
+        return FID_OK;
+    }
     hipLaunchKernelGGL(letterbox_kernel, grid, dim3(256), 0, ctx->stream, frames_dev, H, W, out_dev, in_h, in_w, new_h, new_w,
                        (double)W / (double)new_w, (double)H / (double)new_h, area2x);
     FID_HIP(hipGetLastError());
