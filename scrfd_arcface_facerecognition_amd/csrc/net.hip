@@ -357,6 +357,46 @@ __global__ void __launch_bounds__(256) dwconv3x3_lds(const _Float16 *__restrict_
     }
 }
 
+// ---- global depthwise conv (k x k "valid" on a k x k map -> 1 x 1: MobileFaceNet's GDC, 7 x 7 x 512): eight lanes per (image, 8-channel group),
+// lane r sums tap row r (k taps, fp32 fmaf chain from 0), lane 0 then adds bias + the rows in row order (a fixed order: deterministic; NOT
+// dwconv_nhwc's single 49-tap chain, which ran as 2048 threads of 49 dependent steps = 20 us for 0.1 MFLOP).
+__global__ void __launch_bounds__(256) gdc_rows(const _Float16 *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                                                const float *__restrict__ slope, _Float16 *__restrict__ out, int k, int Cp, int act, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = idx >> 3, r = idx & 7;                        // (image, channel group), tap row
+    const int c8 = Cp >> 3;
+    const bool live = g < total;
+    const int n = live ? g / c8 : 0, cg = live ? g - n * c8 : 0;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.f;
+    if (live && r < k) {
+        for (int dx = 0; dx < k; dx++) {
+            const half8 v = *(const half8 *)(in + ((size_t)(n * k + r) * k + dx) * Cp + cg * 8);
+            const float *wr = w + (size_t)(r * k + dx) * Cp + cg * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[i] = fmaf((float)v[i], wr[i], acc[i]);
+        }
+    }
+    float sum[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) sum[i] = live ? bias[cg * 8 + i] : 0.f;
+    for (int rr = 0; rr < k; rr++)                              // rows in order, read from the lane that holds them (k <= 8)
+#pragma unroll
+        for (int i = 0; i < 8; i++) sum[i] += __shfl(acc[i], (threadIdx.x & ~7) + rr, 64);
+    if (live && r == 0) {
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float a = sum[i];
+            if (act == ACT_RELU) a = fmaxf(a, 0.f);
+            else if (act == ACT_PRELU) a = a > 0.f ? a : a * slope[cg * 8 + i];
+            o[i] = (_Float16)a;
+        }
+        *(half8 *)(out + (size_t)n * Cp + cg * 8) = o;
+    }
+}
+
 // reads `n16` 16-byte words (tuning only: brings a layer's input back into L2 / the Infinity Cache after the cache flush, where the
 // producing layer would have left it)
 __global__ void __launch_bounds__(256) touch_kernel(const uint4 *__restrict__ p, size_t n16, unsigned *sink) {
@@ -689,6 +729,13 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
         case OP_DWCONV: {
             const TensorView src = view(net, op[W_SRC], first);
             const long long total = (long long)batch * dst.H * dst.W * (dst.Cp / 8);
+            static const bool gdc_serial = getenv("FID_GDC_SERIAL") != nullptr;     // A/B: the one-chain kernel
+            if (op[W_KH] == op[W_KW] && op[W_KH] <= 8 && op[W_PAD] == 0 && src.H == op[W_KH] && src.W == op[W_KW] && dst.H == 1 && dst.W == 1 && !gdc_serial) {
+                const int groups = batch * (dst.Cp / 8);            // global depthwise conv: one output pixel per image
+                hipLaunchKernelGGL(gdc_rows, dim3((unsigned)cdiv(groups * 8, 256)), dim3(256), 0, ctx->stream, (const _Float16 *)src.ptr,
+                                   (const float *)(blob + op[W_WOFF]), bias, slope, (_Float16 *)dst.ptr, op[W_KH], dst.Cp, op[W_ACT], groups);
+                break;
+            }
             static const bool dw_global = getenv("FID_DW_GLOBAL") != nullptr;      // A/B: the kernel without the LDS tile everywhere
             // launches with enough pixels take the LDS-tiled kernel (below ~50 k pixels a launch is latency-bound either way: SCRFD-500M on ONE frame measured
             // 1.4 % slower with it, on 32 frames 1.3 % faster; MobileFaceNet's 56 x 56 x 128 layer at 32 faces 41 -> 27.6 us)
