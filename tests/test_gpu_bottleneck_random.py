@@ -1,0 +1,78 @@
+"""GPU parity on RANDOM shapes: the fused bottleneck (csrc/mbf_block.hip), the 32 / 64-channel fused residual block (csrc/conv_bb.hip) and the
+LDS-tiled depthwise kernel (net.hip dwconv3x3_lds) against the fp32 oracle -- odd maps, channel counts that are not multiples of 32, partial
+tiles, both strides, more (tile, cout block) items than CUs."""
+import numpy as np
+import pytest
+
+from oracle import align, nets as onets
+from scrfd_arcface_facerecognition_amd import archs
+from scrfd_arcface_facerecognition_amd.archs import Conv, Net
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from scrfd_arcface_facerecognition_amd._lib import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def run(ctx, net, P, images, out):
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    cn = CompiledNet(ctx, net, P, max_batch=len(images))
+    cn.run(images)
+    got = cn.read(out, len(images))
+    cn.close()
+    ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))[out], (0, 2, 3, 1))
+    assert got.shape == ref.shape
+    return np.abs(got - ref).max() / (np.abs(ref).max() + 1e-6)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_bottleneck(ctx, seed):
+    from scrfd_arcface_facerecognition_amd import lower
+    rng = np.random.default_rng(4000 + seed)
+    hw = (int(rng.integers(5, 61)), int(rng.integers(5, 61)))
+    cin = int(rng.choice([24, 32, 64, 88, 128, 160, 256]))
+    g = int(rng.choice([32, 48, 96, 128, 200, 256, 384, 512]))
+    stride = int(rng.integers(1, 3))
+    res = bool(rng.integers(0, 2)) and stride == 1
+    cout = cin if res else int(rng.choice([16, 40, 64, 128, 144, 256]))
+    batch = int(rng.choice([1, 2, 3, 11]))
+    acts = [str(rng.choice(["prelu", "relu", "none"])) for _ in range(3)]
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 64, act="relu"))
+    net.add(Conv("x", "s", 64, cin, k=1, pad=0, act="prelu"))
+    net.add(Conv("b.pw1", "x", cin, g, k=1, pad=0, act=acts[0]))
+    net.add(Conv("b.dw", "b.pw1", g, g, stride=stride, groups=g, act=acts[1]))
+    net.add(Conv("b.pw2", "b.dw", g, cout, k=1, pad=0, act=acts[2], res="x" if res else None))
+    net.outputs = ["b.pw2"]
+    P = archs.synth_params(net, seed=seed)
+    fused = sum(int(r[0]) == 8 for r in lower.lower(net, P).ops)
+    images = rng.integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    err = run(ctx, net, P, images, "b.pw2")
+    assert fused == 1, (hw, cin, g, cout, stride, res)          # every shape drawn here is one the fused kernel takes
+    assert err < 8e-3, (hw, cin, g, cout, stride, res, batch, acts, err)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_residual_block_and_depthwise(ctx, seed):
+    """a fused residual block (32 or 64 stored channels) followed by a stride-1 depthwise layer large enough for the LDS-tiled kernel"""
+    rng = np.random.default_rng(5000 + seed)
+    hw = (int(rng.integers(12, 120)), int(rng.integers(12, 120)))
+    planes = int(rng.choice([16, 24, 32, 40, 56, 64]))
+    batch = int(rng.integers(1, 4)) if hw[0] * hw[1] > 4000 else int(rng.integers(8, 14))
+    act2 = str(rng.choice(["relu", "none"]))
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, planes, act="relu"))
+    net.add(Conv("b.conv1", "s", planes, planes, act="relu"))
+    net.add(Conv("b.conv2", "b.conv1", planes, planes, act=act2, res="s"))
+    net.add(Conv("p", "b.conv2", planes, 64, k=1, pad=0, act="prelu"))
+    net.add(Conv("d", "p", 64, 64, groups=64, act=str(rng.choice(["prelu", "relu", "none"]))))
+    net.outputs = ["d"]
+    P = archs.synth_params(net, seed=100 + seed)
+    images = rng.integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    err = run(ctx, net, P, images, "d")
+    assert err < 8e-3, (hw, planes, batch, act2, err)
