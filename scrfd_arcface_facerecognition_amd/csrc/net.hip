@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) gdc_rows(const _Float16 *__restrict__ in,
     for (int i = 0; i < 8; i++) sum[i] = live ? bias[cg * 8 + i] : 0.f;
     for (int rr = 0; rr < k; rr++)                              // rows in order, read from the lane that holds them (k <= 8)
 #pragma unroll
-        for (int i = 0; i < 8; i++) sum[i] += __shfl(acc[i], (threadIdx.x & ~7) + rr, 64);
+        for (int i = 0; i < 8; i++) sum[i] += __shfl(acc[i], (threadIdx.x & 63 & ~7) + rr, 64);
     if (live && r == 0) {
         half8 o;
 #pragma unroll
