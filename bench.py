@@ -125,11 +125,20 @@ def mfma_roofline(pipe, frames_dev, batch, F):
             best = ms if best is None else np.minimum(best, ms)
         t, fl, by, k = 0.0, 0.0, 0.0, 0
         by_name = {nd.name: nd for nd in cn.net.nodes}
+        # a block's shortcut conv that its stride-2 conv absorbed at this batch size (a generation-12 pick: csrc/net.h W_X_W2OFF) is not launched:
+        # its FLOPs still count (they are computed, as extra K-steps), its tensor traffic does not exist, its (event-pair) time is not a launch's
+        picks = {(p["op"], p["batch"]): p["gen"] for p in cn.plans()}
+        absorbed = {oi for oi in range(len(cn.low.ops))
+                    if int(cn.low.ops[oi, 0]) == OP_CONV and int(cn.low.ops[oi, 23]) == 0 and int(cn.low.ops[oi, 29]) > 0
+                    and picks.get((int(cn.low.ops[oi, 29]) - 1, n)) == 12}
         for oi, names in enumerate(cn.low.op_nodes):
             if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK):
                 continue
             macs = sum(node_macs(cn.net, by_name[nm]) for nm in names)
-            t += float(best[oi]); fl += 2.0 * macs * n; by += op_bytes(cn, oi, n); k += 1
+            fl += 2.0 * macs * n
+            if oi in absorbed:
+                continue
+            t += float(best[oi]); by += op_bytes(cn, oi, n); k += 1
         hbm_floor, mfma_floor = by / (PEAK_HBM_GBS * 1e9) * 1e3, fl / (PEAK_FP16_TFLOPS * 1e12) * 1e3
         per_net[name] = {"ms": round(t, 4), "tflops": round(fl / t / 1e9, 1), "gbs": round(by / t / 1e6, 1), "launches": k,
                          "gflop": round(fl / 1e9, 1), "gbytes": round(by / 1e9, 3),

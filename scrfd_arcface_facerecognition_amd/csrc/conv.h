@@ -22,6 +22,13 @@ struct ConvArgs {
     void *out;          // fp16/fp32 [B, Ho, Wo, Cout_p]
     void *out2;         // fused shortcut + stride-2 conv (lower.py): second fp16 output [B, Ho, Wo, Cout_p] fed by weight / bias rows Cout_p .. w_rows-1 (no activation), or NULL
     float *partial;     // split-K slabs fp32 [ksplit][M][Cout_p]
+    // fused shortcut (lower.py; generation 2 only): after the kh*kw taps the K axis continues with T2 taps of a SECOND tensor -- the block input x,
+    // fp16 [B, H2, W2, Cin2_p] -- read at pixel (oy * s2 + t2 / kw2, ox * s2 + t2 % kw2): the 1x1 / stride-2 (T2 = 1) or average-pool + 1x1
+    // (T2 = 4: a 2x2 / stride-2 kernel) shortcut conv of a residual block as extra K-steps of the conv that adds it.  Weight rows are
+    // [kh*kw * Cin_p | T2 * Cin2_p] halfs (krow).  in2 = NULL: a plain conv.
+    const void *in2;
+    unsigned in2_bytes;
+    int H2, W2, Cin2_p, T2, kw2, s2, nchunk2, krow;
     unsigned long long *amax;  // CF_ARGMAX: packed (sortable(value) << 32 | ~(amax_col0 + column)) per row
     int amax_col0;             // CF_ARGMAX: global index of column 0 (gallery shards)
     int H, W, Cin_p, Ho, Wo, Cout_p, w_rows;

@@ -384,18 +384,22 @@ __global__ void __launch_bounds__(256, (NS * (BM + (BN + 256 / (BK / 8) - 1) / (
 
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.w_bytes, 0x00020000);
+    const auto rs_in2 = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in2 ? a.in2 : a.in), 0, a.in2 ? a.in2_bytes : a.in_bytes, 0x00020000);
+    const int krow = a.in2 ? a.krow : a.T * a.Cin_p;            // halfs per weight row
 
-    int a_off[A_LD];
+    int a_off[A_LD], a_off2[A_LD];                               // (a_off2: the pixel's first shortcut tap in the second tensor; -1: no pixel)
     unsigned a_mask[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; i++) {
         const int m = tm * BM + i * RPP + lrow;
         a_off[i] = 0;
+        a_off2[i] = -1;
         a_mask[i] = 0;
         if (m < a.M) {
             const Pix p = decompose(a, m);
             const int iy0 = p.oy * a.stride - a.pad, ix0 = p.ox * a.stride - a.pad;
             a_off[i] = ((p.n * a.H + iy0) * a.W + ix0) * a.Cin_p + my_chunk * 8;
+            if (a.in2) a_off2[i] = ((p.n * a.H2 + p.oy * a.s2) * a.W2 + p.ox * a.s2) * a.Cin2_p + my_chunk * 8;
             unsigned mask = 0;
             for (int t = 0; t < a.T; t++) {
                 const int dy = t / a.kw, dx = t - dy * a.kw;
@@ -408,27 +412,41 @@ __global__ void __launch_bounds__(256, (NS * (BM + (BN + 256 / (BK / 8) - 1) / (
 #pragma unroll
     for (int i = 0; i < B_LD; i++) {
         const int row = i * RPP + lrow, co = tn * BN + row;
-        b_off[i] = (row < BN && co < a.w_rows) ? co * a.T * a.Cin_p + my_chunk * 8 : -1;
+        b_off[i] = (row < BN && co < a.w_rows) ? co * krow + my_chunk * 8 : -1;
     }
 
     const int ks_begin = split * a.ksteps_per_split;
     const int ks_end = min(a.ksteps, ks_begin + a.ksteps_per_split);
     const int nk = ks_end - ks_begin;
     // wave-uniform position of the next stage to issue: tap (dy, dx) and channel chunk
-    int tap = ks_begin / a.nchunk, ch = ks_begin - tap * a.nchunk;
+    // (the shortcut's K-steps follow the main taps: tap = T + t2)
+    const int ks_main = a.T * a.nchunk;
+    int tap = ks_begin < ks_main ? ks_begin / a.nchunk : a.T + (ks_begin - ks_main) / a.nchunk2;
+    int ch = ks_begin < ks_main ? ks_begin - tap * a.nchunk : (ks_begin - ks_main) - (tap - a.T) * a.nchunk2;
     int tdy = tap / a.kw, tdx = tap - tdy * a.kw;
 
     // one DMA instruction (1 KB) of the stage being issued: j < A_LD -> activation rows, else weight rows
     int adelta = 0, bdelta = 0;
     auto stage_begin = [&]() {
-        adelta = (tdy * a.W + tdx) * a.Cin_p + ch * BK;
-        bdelta = tap * a.Cin_p + ch * BK;
+        if (tap < a.T) {
+            adelta = (tdy * a.W + tdx) * a.Cin_p + ch * BK;
+            bdelta = tap * a.Cin_p + ch * BK;
+        } else {                                                // a shortcut tap: (t2 / kw2, t2 % kw2) in the second tensor
+            const int t2 = tap - a.T, dy2 = t2 / a.kw2, dx2 = t2 - dy2 * a.kw2;
+            adelta = (dy2 * a.W2 + dx2) * a.Cin2_p + ch * BK;
+            bdelta = a.T * a.Cin_p + t2 * a.Cin2_p + ch * BK;
+        }
     };
     auto stage_piece = [&](int slot, int j) {
         char *dst = smem + slot * STAGE + wave * 1024;
         if (j < A_LD) {
-            const unsigned vo = ((a_mask[j] >> tap) & 1u) ? (unsigned)(a_off[j] + adelta) * 2u : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 4096), 16, vo, 0, 0, 0);
+            if (tap < a.T) {
+                const unsigned vo = ((a_mask[j] >> tap) & 1u) ? (unsigned)(a_off[j] + adelta) * 2u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 4096), 16, vo, 0, 0, 0);
+            } else {                                            // (wave-uniform branch: the same number of DMA instructions either way)
+                const unsigned vo = a_off2[j] >= 0 ? (unsigned)(a_off2[j] + adelta) * 2u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (__attribute__((address_space(3))) void *)(dst + j * 4096), 16, vo, 0, 0, 0);
+            }
         } else {
             const int i = j - A_LD;
             const unsigned vo = b_off[i] >= 0 ? (unsigned)(b_off[i] + bdelta) * 2u : OOB;
@@ -436,7 +454,7 @@ __global__ void __launch_bounds__(256, (NS * (BM + (BN + 256 / (BK / 8) - 1) / (
         }
     };
     auto stage_end = [&]() {
-        if (++ch == a.nchunk) {
+        if (++ch == (tap < a.T ? a.nchunk : a.nchunk2)) {
             ch = 0;
             ++tap;
             if (++tdx == a.kw) { tdx = 0; ++tdy; }
@@ -751,9 +769,9 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
     ConvPlan p{};
     static const bool use_v1 = getenv("FID_CONV_V1") != nullptr;
     auto tiles = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.Cout_p, bn); };
-    if (!use_v1) {
+    if (!use_v1 || a.in2) {
         // ---- generation 2: LDS-DMA ring, BK = 64 over the flattened (tap, channel) axis ----
-        p.gen = 2; p.bk = (a.Cin_p % 64 == 0) ? 64 : 32; p.ns = 4;
+        p.gen = 2; p.bk = (a.Cin_p % 64 == 0 && (!a.in2 || a.Cin2_p % 64 == 0)) ? 64 : 32; p.ns = 4;
         p.bm = 128;
         if (a.Cout_p % 128 == 0) p.bn = 128;
         else if (a.Cout_p % 96 == 0) p.bn = 96;
@@ -802,7 +820,18 @@ ConvPlan conv_plan(const ConvArgs &a, int num_cus, bool allow_split) {
     return p;
 }
 
+static std::vector<ConvPlan> conv_candidates_all(const ConvArgs &a, int num_cus, bool allow_split);
+
 std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split) {
+    std::vector<ConvPlan> all = conv_candidates_all(a, num_cus, allow_split);
+    if (!a.in2) return all;
+    std::vector<ConvPlan> only;                      // fused shortcut (extra K-steps on a second tensor): the LDS-DMA implicit GEMM only
+    for (const ConvPlan &c : all)
+        if (c.gen == 2 && a.Cin2_p % c.bk == 0) only.push_back(c);
+    return only;
+}
+
+static std::vector<ConvPlan> conv_candidates_all(const ConvArgs &a, int num_cus, bool allow_split) {
     if (a.out2) {                                   // fused shortcut + stride-2 conv: one kernel takes it
         std::vector<ConvPlan> only;
         if (conv_s2_applicable(a)) { ConvPlan d{}; d.gen = 10; d.ksplit = 1; d.bm = 128; d.bn = a.w_rows; d.bk = 32; only.push_back(d); }
@@ -948,6 +977,14 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     FID_REQUIRE(a.in_bytes <= OOB && a.w_bytes <= OOB, "conv: tensor larger than 2 GiB; lower the batch");
     a.nchunk = a.Cin_p / plan.bk;
     a.ksteps = cdiv(a.T * a.Cin_p, plan.bk);
+    if (a.in2) {                                                // fused shortcut: T2 more taps on the second tensor (generation 2 only)
+        FID_REQUIRE(plan.gen == 2, "conv: the fused shortcut runs on generation 2 only (plan names %d)", plan.gen);
+        FID_REQUIRE(a.T2 >= 1 && a.T + a.T2 <= 32 && a.kw2 >= 1 && a.s2 >= 1 && a.Cin2_p % plan.bk == 0 && a.in2_bytes <= OOB,
+                    "conv: fused shortcut with %d taps of %d channels (BK = %d)", a.T2, a.Cin2_p, plan.bk);
+        a.nchunk2 = a.Cin2_p / plan.bk;
+        a.krow = a.T * a.Cin_p + a.T2 * a.Cin2_p;
+        a.ksteps += a.T2 * a.nchunk2;
+    }
     a.ksplit = plan.ksplit;
     a.ksteps_per_split = cdiv(a.ksteps, a.ksplit);
     a.ksplit = cdiv(a.ksteps, a.ksteps_per_split);

@@ -44,6 +44,14 @@ enum : int {
     // OP_CONV fused with the block's shortcut (lower.py; conv_s2.hip DUAL): second output's tensor id + 1 (0: plain conv), its activation,
     // padded couts of the first output; W_F_MACS_LO then holds the shortcut's MACs per image
     W_X_DST2 = 20, W_X_ACT2 = 21, W_X_COUT1P = 22,
+    // OP_CONV fused with the block's shortcut CONV as extra K-steps on a second input tensor (lower.py; conv.hip generation 2): tensor id + 1 of
+    // the block input (0: none), its taps (1: a 1x1 conv; 4: average pool + 1x1 = a 2x2 kernel), their row length, the sampling stride;
+    W_X_SRC2 = 23, W_X_T2 = 24, W_X_KW2 = 25, W_X_S2 = 28,
+    // ... both forms are in the table: the shortcut conv stays an op of its own (its word 29 = index + 1 of the conv that can absorb it) and the
+    // absorbing conv carries a SECOND weight image with rows [kh*kw * Cin_p | taps * Cin2_p] (word 29), the summed bias row (word 30) and the
+    // shortcut's op index + 1 (word 31).  The autotuner decides per batch size: a generation-12 pick = generation 2 on the second image with the
+    // shortcut as extra K-steps (the shortcut op is then skipped), any other pick = the plain conv + the shortcut op.
+    W_X_W2OFF = 29, W_X_B2OFF = 30, W_X_SCOP = 31,
 };
 
 // int32 word indices of one tensor record (FID_TENSOR_WORDS = 8 words)

@@ -540,8 +540,14 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             break;
         }
         case OP_CONV: {
+            if (op[W_X_SRC2] == 0 && op[W_X_W2OFF] > 0) {        // a block's shortcut conv that its consumer may absorb (lower.py): word 29 = that conv's op index + 1
+                const int cons = op[W_X_W2OFF] - 1;
+                auto itc = net->tuned[cons].find(batch);
+                if (itc != net->tuned[cons].end() && itc->second.gen == 12 && net->plan_ok[cons].count(batch)) break;   // absorbed at this batch size: nothing to do
+            }
             const TensorView src = view(net, op[W_SRC], first);
-            ConvArgs a{};
+            ConvArgs a{}, af{};
+            bool has_sc = false;
             a.in = src.ptr;
             a.w = blob + op[W_WOFF];
             a.bias = bias;
@@ -566,8 +572,38 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
             }
             a.in_bytes = (unsigned)((size_t)batch * src.H * src.W * src.Cp * 2);
             a.w_bytes = (unsigned)op[W_WBYTES];
-            a.partial = (float *)partial_ws;
-            a.rev = net->alternate && op[W_SRC] >= 0 && !net->tdir[op[W_SRC]];
+            if (op[W_X_SRC2] > 0) {                              // the block's shortcut conv as extra K-steps on the block input
+                const TensorView x2 = view(net, op[W_X_SRC2] - 1, first);
+                FID_REQUIRE(x2.dtype == 0 && op[W_X_T2] >= 1 && op[W_X_KW2] >= 1 && op[W_X_S2] >= 1 && op[W_X_DST2] == 0 &&
+                            (dst.H - 1) * op[W_X_S2] + (op[W_X_T2] / op[W_X_KW2] - 1) < x2.H && (dst.W - 1) * op[W_X_S2] + op[W_X_KW2] - 1 < x2.W,
+                            "op %d: bad fused shortcut-conv record", oi);
+                FID_REQUIRE(op[W_X_W2OFF] > 0 && op[W_X_B2OFF] > 0 && op[W_X_SCOP] > 0 && op[W_X_SCOP] <= oi && op[W_RES] >= 0, "op %d: fused shortcut-conv record without its second image", oi);
+                // the fused form (a generation-12 pick): second weight image [kh*kw * Cin_p | T2 * Cin2_p], summed bias, no residual
+                af = a;
+                af.in2 = x2.ptr; af.H2 = x2.H; af.W2 = x2.W; af.Cin2_p = x2.Cp; af.T2 = op[W_X_T2]; af.kw2 = op[W_X_KW2]; af.s2 = op[W_X_S2];
+                af.in2_bytes = (unsigned)((size_t)batch * x2.H * x2.W * x2.Cp * 2);
+                af.w = blob + op[W_X_W2OFF];
+                af.bias = (const float *)(blob + op[W_X_B2OFF]);
+                af.w_bytes = (unsigned)((size_t)op[W_WROWS] * (op[W_KH] * op[W_KW] * src.Cp + op[W_X_T2] * x2.Cp) * 2);
+                af.res = nullptr;
+                has_sc = true;
+            }
+            a.partial = af.partial = (float *)partial_ws;
+            a.rev = af.rev = net->alternate && op[W_SRC] >= 0 && !net->tdir[op[W_SRC]];
+            // every candidate of this op: the plain conv's, and (generation 12) generation 2's with the shortcut as extra K-steps
+            auto all_candidates = [&]() {
+                std::vector<ConvPlan> v = conv_candidates(a, ctx->num_cus, true);
+                static const bool no_sc = getenv("FID_NO_SC_RUNTIME") != nullptr;
+                if (has_sc && !no_sc)
+                    for (ConvPlan c : conv_candidates(af, ctx->num_cus, true)) { c.gen = 12; v.push_back(c); }
+                return v;
+            };
+            auto launch_plan = [&](const ConvPlan &c) -> int {
+                if (c.gen != 12) return conv_launch(ctx, a, c);
+                ConvPlan c2 = c;
+                c2.gen = 2;
+                return conv_launch(ctx, af, c2);
+            };
             ConvPlan plan;
             auto &cache = net->tuned[oi];
             auto it = cache.find(batch);
@@ -576,7 +612,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 // THIS library's candidates for the op (another revision's candidate set, a hand-edited line) and its split-K
                 // workspace -- recomputed here, not taken from the file -- must fit the scratch this run sized
                 bool ok = false;
-                for (const ConvPlan &c : conv_candidates(a, ctx->num_cus, true))
+                for (const ConvPlan &c : all_candidates())
                     if (same_kernel(c, it->second) && c.partial_bytes <= net->partial_cap && (c.ksplit == 1 || partial_ws)) { it->second = c; ok = true; break; }
                 if (!ok && it->second.ksplit == 1) {             // (conv_plan's heuristic pick is not always in the candidate list)
                     const ConvPlan h = conv_plan(a, ctx->num_cus, false);
@@ -591,7 +627,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 // first time this op runs at this batch size: time every candidate kernel on the real
                 // operands (the op is idempotent) and keep the fastest; a split-K plan must win by 10 %
                 // to be preferred (its summation order differs from the unsplit kernels)
-                std::vector<ConvPlan> cands = conv_candidates(a, ctx->num_cus, true);
+                std::vector<ConvPlan> cands = all_candidates();
                 if (const char *fg = getenv("FID_FORCE_GEN")) {      // tests: exercise one kernel family wherever it applies
                     std::vector<ConvPlan> only;
                     for (const ConvPlan &c : cands)
@@ -619,6 +655,20 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 float best = 1e30f;
                 if (cands.empty()) { set_error("op %d: no kernel candidate", oi); return FID_E_STATE; }
                 plan = cands[0];
+                // a plain pick also costs the shortcut conv's launch (it ran a moment ago with its own pick): timed here, added to the plain candidates
+                float t_sc = 0.f;
+                if (has_sc) {
+                    t_sc = 1e30f;
+                    for (int rep = 0; rep < 3; rep++) {
+                        FID_HIP(hipEventRecord(e0, ctx->stream));
+                        FID_TRY(run_op(ctx, net, op[W_X_SCOP] - 1, images - (size_t)first * net->in_h * net->in_w * 3, first, batch, partial_ws));
+                        FID_HIP(hipEventRecord(e1, ctx->stream));
+                        FID_HIP(hipEventSynchronize(e1));
+                        float ms = 0;
+                        FID_HIP(hipEventElapsedTime(&ms, e0, e1));
+                        t_sc = std::min(t_sc, ms);
+                    }
+                }
                 for (const ConvPlan &c : cands) {
                     if (c.partial_bytes > net->partial_cap) continue;
                     float tmin = 1e30f;
@@ -631,7 +681,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                                 hipLaunchKernelGGL(touch_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, ctx->stream, (const uint4 *)a.in, (size_t)a.in_bytes / 16, (unsigned *)nullptr);
                         }
                         FID_HIP(hipEventRecord(e0, ctx->stream));
-                        FID_TRY(conv_launch(ctx, a, c));
+                        FID_TRY(launch_plan(c));
                         FID_HIP(hipEventRecord(e1, ctx->stream));
                         FID_HIP(hipEventSynchronize(e1));
                         float ms = 0;
@@ -639,6 +689,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                         if (rep > 0) tmin = std::min(tmin, ms);
                     }
                     float score = c.ksplit > 1 ? tmin * 1.1f : tmin;
+                    if (has_sc && c.gen != 12) score += t_sc;
                     // FID_TUNE_SHARE = s (0 .. 1; plans for two-lane deployments, tools/make_plan.sh): a launch on a fraction f of the CUs scores
                     // t (1 - s (1 - f)) -- the CUs it leaves free run the other lane's kernels.  Measured on IResNet's 7x7 layers at 64 faces:
                     // conv_ks MOSAIC (128 workgroups, 38 us) against generation 2 (392 workgroups, 36 us): the step is 1.3 % shorter with MOSAIC.
@@ -671,7 +722,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 if (conv_direct_applicable(a)) { plan.gen = 0; plan.ksplit = 1; }
             }
             FID_TRY(set_alt_weights(ctx, net, oi, a, plan));
-            FID_TRY(conv_launch(ctx, a, plan));
+            FID_TRY(launch_plan(plan));
             net->tdir[op[W_DST]] = (char)(a.rev && conv_walks_reverse(plan));
             if (op[W_X_DST2] > 0) net->tdir[op[W_X_DST2] - 1] = net->tdir[op[W_DST]];
             break;
@@ -910,6 +961,11 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
                                                      op[W_B_B1] >= 0 && (size_t)op[W_B_B1] + ((op[W_FLAGS] & CF_BORDER) ? 9 : 1) * 256 <= blob_bytes &&
                                                      op[W_B_B2] >= 0 && (size_t)op[W_B_B2] + 256 <= blob_bytes &&
                                                      (op[W_B_ACT1] == ACT_RELU || (op[W_B_ACT1] == ACT_PRELU && op[W_B_S1] >= 0 && (size_t)op[W_B_S1] + 256 <= blob_bytes)))) &&
+                        (op[W_TYPE] != OP_CONV || op[W_X_SRC2] == 0 || (op[W_X_SRC2] > 0 && op[W_X_SRC2] <= n_tensors && op[W_X_T2] >= 1 && op[W_X_KW2] >= 1 &&
+                                                                           op[W_X_T2] % op[W_X_KW2] == 0 && op[W_X_S2] >= 1 && op[W_X_DST2] == 0 &&
+                                                                           op[W_X_W2OFF] > 0 && op[W_X_B2OFF] > 0 && op[W_X_SCOP] >= 1 && op[W_X_SCOP] <= oi &&
+                                                                           (size_t)op[W_X_B2OFF] + (size_t)op[W_WROWS] * 4 <= blob_bytes)) &&
+                        (op[W_TYPE] != OP_CONV || op[W_X_SRC2] != 0 || op[W_X_W2OFF] == 0 || (op[W_X_W2OFF] > oi + 1 && op[W_X_W2OFF] <= n_ops)) &&
                         (op[W_TYPE] != OP_DWPW || (op[W_D_WOFF] >= 0 && op[W_D_BOFF] >= 0 && op[W_WOFF] >= 0 && (op[W_D_ACT] != ACT_PRELU || op[W_D_SOFF] >= 0))) &&
                         (op[W_TYPE] != OP_MBBLOCK || (op[W_M_W1] >= 0 && op[W_M_B1] >= 0 && op[W_M_DW] >= 0 && op[W_M_DWB] >= 0 && op[W_WOFF] >= 0 && op[W_M_GP] > 0 &&
                                                       op[W_M_GP] % 32 == 0 && (size_t)op[W_M_DW] + (size_t)9 * op[W_M_GP] * 4 <= blob_bytes &&

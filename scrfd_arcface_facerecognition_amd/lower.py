@@ -80,6 +80,35 @@ class Lowered:
         self.fused_groups: Dict[str, list] = {}   # fused op name -> graph nodes it covers
 
 
+def _shortcut_target(net, i, tensors, tid, shp):
+    """node i = a residual block's shortcut conv (1x1, stride s, + BN, no activation) whose only consumer is the residual add of a later
+    3x3 conv of the same output shape that the implicit-GEMM kernel can extend by K-steps on the block input: that conv node, or None"""
+    n = net.nodes[i]
+    if not (n.k == 1 and n.pad == 0 and n.stride in (1, 2) and n.act == "none" and n.res is None and not n.pre_bn and not n.pre_avgpool
+            and not n.res_up2 and n.src != "input" and n.name not in net.outputs):
+        return None
+    users = [x for x in net.nodes if getattr(x, "src", None) == n.name or getattr(x, "res", None) == n.name]
+    if len(users) != 1:
+        return None
+    m = users[0]
+    if not (m.kind == "conv" and m.res == n.name and m.src != n.name and m.groups == 1 and m.k == 3 and m.pad == 1 and m.stride == 2 and not m.pre_bn
+            and not m.pre_avgpool and not m.res_up2 and net.nodes.index(m) > i and shp[m.name] == shp[n.name]):
+        return None
+    x_t, y_t = tensors[tid[n.src]], None
+    if m.src not in tid:                                  # (conv2's input is lowered after the shortcut: its padded width is its own cout rounded up)
+        src_node = next(x for x in net.nodes if x.name == m.src)
+        cin_p = _rup(src_node.cout, CPAD)
+    else:
+        cin_p = tensors[tid[m.src]][1]
+    # the sampled pixel (oy * s, ox * s) must exist, the channel counts must suit a 32- or 64-wide K-step of the LDS-DMA implicit GEMM
+    _, ho, wo = shp[m.name]
+    if x_t[4] != 0 or x_t[1] % 32 or cin_p % 32 or (ho - 1) * n.stride >= x_t[2] or (wo - 1) * n.stride >= x_t[3]:
+        return None
+    if n.stride != m.stride:
+        return None
+    return m
+
+
 def _mbf_block(net, i, tensors, tid, shp):
     """nodes i, i+1, i+2 = pointwise 1x1 -> depthwise 3x3 -> pointwise 1x1 [+ the first one's input] in the shapes csrc/mbf_block.hip takes
     (mbf_block_applicable): (depthwise node, second pointwise node) or None"""
@@ -259,10 +288,19 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
         fused_upto = 4
 
     skip = set()
+    pending_sc = {}                                   # conv2 name -> its block's shortcut conv node, fused as extra K-steps (below)
     for ni_, n in enumerate(net.nodes):
         if ni_ < fused_upto or ni_ in skip:
             continue
         nxt = net.nodes[ni_ + 1] if ni_ + 1 < len(net.nodes) else None
+        if (n.kind == "conv" and n.groups == 1 and n.src != "input" and not os.environ.get("FID_NO_SC_FUSE")
+                and _shortcut_target(net, ni_, tensors, tid, shp) is not None):
+            # IResNet's block shortcut (1x1 / stride-2 conv + BN on the block input x) feeds nothing but the residual add of the block's stride-2
+            # conv2: it CAN run as extra K-steps of that conv (one more "tap" that reads x at (2 oy, 2 ox): csrc/conv.hip generation 2,
+            # ConvArgs::in2).  Both forms are lowered -- this op as it is, and conv2 with a second weight image [9 Cin | Cx] + summed bias --
+            # and the autotuner decides per batch size (the fused form is a generation-12 pick of conv2; this op is then skipped): at 64
+            # faces every fused pair wins 5-12 us, at 500 the weights-in-registers kernels the fused form cannot use win instead.
+            pending_sc[_shortcut_target(net, ni_, tensors, tid, shp).name] = (n, len(ops))     # (this op is emitted next: its index)
         if n.kind == "conv" and n.src == "input":
             assert n.k == 3 and n.pad == 1 and n.groups == 1 and not n.pre_bn and n.res is None
             cout, (_, ho, wo) = n.cout, shp[n.name]
@@ -426,16 +464,30 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             pad = n.pad
             ncls = bias_tab.shape[0]
             Wp = pack_weights(W, cin_p, cout_p)
+            sc, sc_op = pending_sc.pop(n.name, (None, -1))
             woff, wbytes = blob.add(Wp)
             bt = np.zeros((ncls, cout_p), dtype=np.float32)
             bt[:, :cout] = bias_tab
             boff, _ = blob.add(bt)
+            if sc is not None:                                        # second image: weight rows [9 * Cin_p | Cin2_p], one bias row = both biases
+                Wsc, bsc = folded(sc)
+                x_t = tensors[tid[sc.src]]
+                assert ncls == 1 and ops[sc_op][2] == tid[sc.name]
+                W2p = np.concatenate([Wp.reshape(cout_p, -1), pack_weights(Wsc, x_t[1], cout_p).reshape(cout_p, -1)], axis=1)
+                w2off = blob.add(W2p)[0]
+                bt2 = np.zeros((1, cout_p), dtype=np.float32)
+                bt2[0, :cout] = bias_tab[0] + bsc
+                b2off = blob.add(bt2)[0]
             soff = blob.add(padded(P[n.wname + ".prelu"], cout_p))[0] if n.act == "prelu" else -1
             flags = (CF_BORDER if ncls == 9 else 0) | (CF_RES_UP2 if n.res_up2 else 0)
             dst = new_tensor(n.name, cout, ho, wo)
             emit(n.name, type=OP_CONV, src=tid[n.src], dst=dst, res=tid[n.res] if n.res else -1, kh=k, kw=k,
                  stride=stride, pad=pad, cin=cin, cout=cout, act=ACT[n.act], flags=flags, woff=woff,
                  wbytes=wbytes, boff=boff, soff=soff, wrows=cout_p)
+            if sc is not None:                                        # csrc/net.h W_X_SRC2 ..: block input, taps, row length, stride, second images, the shortcut's op
+                r = ops[-1]
+                r[23], r[24], r[25], r[28], r[29], r[30], r[31] = tid[sc.src] + 1, 1, 1, sc.stride, w2off, b2off, sc_op + 1
+                ops[sc_op][29] = len(ops)                             # the shortcut op knows the conv that may absorb it (index + 1)
         elif n.kind == "conv":                                        # depthwise
             assert n.groups == n.cin == n.cout and not n.pre_bn and not n.pre_avgpool and n.res is None
             c = n.cin
@@ -546,6 +598,8 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
         for w in (1, 3):
             if rec[w] >= 0:
                 last_use[base[rec[w]]] = oi
+        if rec[0] == OP_CONV and rec[23] > 0:         # the fused shortcut conv's input (the block input)
+            last_use[base[rec[23] - 1]] = oi
     keep = {tid[o] for o in net.outputs}
     slot_of = [-1] * n_t
     slot_size: List[int] = []

@@ -321,3 +321,45 @@ def test_fused_bottleneck(ctx, monkeypatch, fuse, hw, cin, g, cout, stride, res,
     ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["b.pw2"], (0, 2, 3, 1))
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3
+
+
+# IResNet's downsampling block: the shortcut (1x1 / stride-2 conv + BN on the block input) as extra K-steps of the stride-2 conv2 that adds it
+# (lower.py keeps both forms in the table, the autotuner decides per batch size; conv.hip generation 2 with a second input tensor = a generation-12
+# pick of conv2, the shortcut op is then skipped).  "fused": generation 12 forced; "tuned": whatever the tuner picks; "plain": the lowering without
+# the second weight image -- all against the oracle: IResNet-50's four shapes scaled down, odd maps, channel counts whose K-step must be 32 wide
+@pytest.mark.parametrize("mode", ["fused", "tuned", "plain"])
+@pytest.mark.parametrize("hw,cin,cout,batch", [((56, 56), 64, 64, 2), ((28, 28), 64, 128, 3), ((37, 45), 64, 96, 2), ((14, 14), 256, 512, 5), ((30, 22), 88, 160, 1)])
+def test_fused_shortcut_conv(ctx, monkeypatch, mode, hw, cin, cout, batch):
+    from scrfd_arcface_facerecognition_amd import lower
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    if mode == "plain":
+        monkeypatch.setenv("FID_NO_SC_FUSE", "1")
+    if mode == "fused":
+        monkeypatch.setenv("FID_FORCE_GEN", "12")            # (only conv2 has generation-12 candidates: every other op tunes as usual)
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 64, act="prelu"))
+    x = "s"
+    if cin != 64:
+        net.add(Conv("x", "s", 64, cin, k=1, pad=0, act="prelu"))
+        x = "x"
+    net.add(Conv("b.down", x, cin, cout, k=1, stride=2, pad=0))
+    net.add(Conv("b.conv1", x, cin, cout, act="prelu", pre_bn=True))
+    net.add(Conv("b.conv2", "b.conv1", cout, cout, stride=2, res="b.down"))
+    net.outputs = ["b.conv2"]
+    P = archs.synth_params(net, seed=61)
+    low = lower.lower(net, P)
+    assert (sum(int(r[0]) == 2 and int(r[23]) > 0 for r in low.ops) == 1) == (mode != "plain") and "b.down" in low.op_names
+    images = np.random.default_rng(14).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    for _ in range(3):                                      # the first run tunes (the shortcut op runs); later runs skip it when conv2's pick is generation 12
+        cn.run(images)
+    got = cn.read("b.conv2", batch)
+    picks = {p["name"]: p["gen"] for p in cn.plans()}
+    cn.close()
+    if mode == "fused":
+        assert picks["b.conv2"] == 12
+    if mode == "plain":
+        assert picks["b.conv2"] != 12
+    ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["b.conv2"], (0, 2, 3, 1))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3, picks
