@@ -104,8 +104,14 @@ def op_bytes(cn, oi, n):
         t = tens[tid]
         return int(t[T_H]) * int(t[T_W]) * int(t[T_CP]) * (4 if int(t[T_DTYPE]) == 1 else 2)
     b = tb(int(op[W_DST])) * n + max(0, int(op[W_WBYTES]))
-    if int(op[0]) == 6:                                    # fused residual block (csrc/conv_bb.hip): two 64x9x64 fp16 filter banks; its intermediate map is never stored
-        b += 2 * 64 * 9 * 64 * 2
+    cp_src = int(tens[int(op[W_SRC])][T_CP]) if int(op[W_SRC]) >= 0 else 0
+    if int(op[0]) == 6:                                    # fused residual block (csrc/conv_bb.hip): two Cp x 9 x Cp fp16 filter banks (Cp = 64, or 32 for conv_bb32); its intermediate map is never stored
+        b += 2 * cp_src * 9 * cp_src * 2
+    elif int(op[0]) == 8:                                  # fused bottleneck (csrc/mbf_block.hip): W_WBYTES is the second pointwise conv's; + the first one's weights and the depthwise table
+        gp = int(op[30])
+        b += cp_src * gp * 2 + 9 * gp * 4
+    elif int(op[0]) == 7:                                  # depthwise + pointwise (csrc/dwpw.hip): + the depthwise table
+        b += 9 * cp_src * 4
     b += tb(int(op[W_SRC])) * n if int(op[W_SRC]) >= 0 else cn.in_hw[0] * cn.in_hw[1] * 3 * n
     if int(op[W_RES]) >= 0:
         b += tb(int(op[W_RES])) * n
@@ -223,6 +229,25 @@ def cosine_delta(pipe, frames, rec_net, rec_P, gal_host, thresh, n_check):
             "match_index_agreement": f"{agree}/{n_check}", "cosine_delta_sample": f"{n_check} faces of the timed batch vs the fp32 oracle on identical landmarks"}
 
 
+def detector_agreement(pipe, frames, det_net, det_P, n_frames):
+    """reference models/scrfd.py:140-156 on the fp32 oracle's heads vs the device's fp16 heads of the timed batch (oracle/agreement.py):
+    survivors matched by IoU >= 0.9; a flip is marginal when one quantity within 5e-3 of a decision boundary explains it (score vs
+    conf_thres, suppressing IoU vs iou_thres, score order of an overlapping pair), a cascade when it follows from such a flip."""
+    import torch
+    from oracle import agreement as oagree, align as oalign, nets as onets
+    torch.set_num_threads(host_cores())
+    fused = [pipe.det.read(name, pipe.B) for name in det_net.outputs]
+    per_frame = []
+    for fi in range(n_frames):
+        blob = oalign.blob_from_images([frames[fi]], det_net.in_scale, det_net.in_mean)
+        ref_outs = onets.scrfd_session_outputs(det_net, det_P, blob)
+        per_frame.append(oagree.survivor_agreement(ref_outs, oagree.fused_to_session_outputs(fused, fi), (640, 640), pipe.conf, pipe.iou, margin=5e-3))
+    a = oagree.summarize(per_frame)
+    return {"det_survivor_agreement": {"matched": a["matched"], "marginal_flips": a["marginal_flips"], "cascade_flips": a["cascade_flips"],
+                                       "unexplained": a["unexplained"], "survivors_oracle": a["survivors_a"], "survivors_device": a["survivors_b"],
+                                       "sample": f"all NMS survivors (max_num = 0) of {n_frames} frames of the timed batch, fp32 oracle heads vs device heads, margin 5e-3"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +258,7 @@ def main():
     ap.add_argument("--faces-per-frame", type=int, default=1)
     ap.add_argument("--gallery", type=int, default=0, help="gallery entries (0 = 1000 at N = 1 [cfg 2], 100000 at N > 1 [cfg 3])")
     ap.add_argument("--cpu-frames", type=int, default=512, help="frames of the CPU baseline sample (0 = skip; also skips the side legs)")
+    ap.add_argument("--agree-frames", type=int, default=64, help="frames of the timed batch whose NMS survivors are compared with the fp32 oracle's (~0.1 s each)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the F = 8 and H2D-included side measurements")
     ap.add_argument("--comm", choices=("torch", "native"), default=os.environ.get("FID_COMM", "torch"),
@@ -394,9 +420,19 @@ def main():
             el = float(t.item())
         return el
 
+    # what the plan file really installed: its picks are keyed by ISA name + CU count + layer-table hash + candidate-set
+    # revision, so a file that does not match this box / library installs NOTHING and every op is tuned at start-up instead -- the line says so
+    plan_path = os.environ.get("FID_PLAN") or os.environ.get("FID_PLAN_RO")
+
+    def picks_at(cn, n):
+        return {p["op"] for p in cn.plans() if p["batch"] == n}
+    pre_picks = {"det": picks_at(det, B), "rec": picks_at(rec, B * F)}
     for i in range(len(lanes)):              # every lane tunes its kernels alone on the GPU
         step(i)
         torch.cuda.synchronize()
+    post_picks = {"det": picks_at(det, B), "rec": picks_at(rec, B * F)}
+    plan_picks_loaded = {k: len(v) for k, v in pre_picks.items()}
+    ops_autotuned = {k: len(post_picks[k] - pre_picks[k]) for k in pre_picks}
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -406,6 +442,14 @@ def main():
     elapsed = float(np.median(repeats))
     host_enqueue_ms = float(np.median(enqueue_s)) * 1e3
     log(f"timed regions done: {[round(r / args.steps * 1e3, 3) for r in repeats]} ms/step, median {elapsed / args.steps * 1e3:.3f}")
+    # the same steps on ONE lane (VERDICT r3 item 5 / Weak 9): a kernel change that is slower alone but faster in the two-lane step stays visible
+    one_lane_ms = None
+    if len(lanes) > 1:
+        def step_lane0(i):
+            step(0)
+        one = [timed_region(step_lane0, args.steps) for _ in range(3)]
+        one_lane_ms = float(np.median(one)) / args.steps * 1e3
+        log(f"one lane: {[round(r / args.steps * 1e3, 3) for r in one]} ms/step")
 
     pipe.post.check()
     counts = pipe.post.counts.download()
@@ -438,13 +482,17 @@ def main():
                                    + f"SCRFD-10G + ArcFace-R50, {B} synthetic 640x640 frames per GPU per step, "
                                    f"F={F} face/frame (max_num), {G}-entry gallery, random-init weights (seed 0)",
                        "frames_per_gpu": B, "faces_per_step": faces_total_step, "gallery": G,
-                       "kernel_plan": (os.path.relpath(os.environ.get("FID_PLAN") or os.environ["FID_PLAN_RO"], ROOT)
-                                       if (os.environ.get("FID_PLAN") or os.environ.get("FID_PLAN_RO")) else "autotuned at start-up"),
+                       "kernel_plan": ("autotuned at start-up" if not plan_path else
+                                       os.path.relpath(plan_path, ROOT) if min(plan_picks_loaded.values()) > 0 else
+                                       f"autotuned at start-up (plan key mismatch: {os.path.relpath(plan_path, ROOT)} holds no picks for this device / library revision)"),
+                       "plan_picks_loaded": plan_picks_loaded, "ops_autotuned_at_startup": ops_autotuned,
                        "parallelism": par + (f", {len(lanes)} batches in flight per GPU on separate HIP streams" if len(lanes) > 1 else "")},
             "repeats": len(repeats), "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in repeats],
             "ms_per_step_min": round(min(repeats) / args.steps * 1e3, 4),
             "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
         }
+        if one_lane_ms is not None:
+            out["ms_per_step_1lane"] = round(one_lane_ms, 4)
         if not args.no_roofline:
             log("roofline: per-op HIP-event timing")
             out["roofline"] = mfma_roofline(pipe, frames_dev, B, F)
@@ -455,6 +503,8 @@ def main():
         ctx.sync()
         log("cosine delta vs the oracle")
         out.update(cosine_delta(pipe, frames, rec_net, rec_P, gal_host, thresh, n_check=min(16, B)))
+        log("detector survivor agreement vs the oracle")
+        out.update(detector_agreement(pipe, frames, det_net, det_P, n_frames=min(args.agree_frames, B)))
     if side and not args.no_side_legs:
         torch.cuda.synchronize()
         # ---- side leg 1: H2D included.  Per lane two device frame buffers and one pinned host batch; the upload of the next

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FID_ABI_VERSION 1
+#define FID_ABI_VERSION 2   /* 2: fid_face_gates takes the pose angles as float64 (round 4) */
 
 #define FID_OK 0
 #define FID_E_INVALID (-1)   /* bad argument / shape / table */
@@ -188,21 +188,24 @@ typedef struct fid_gate_config {
 } fid_gate_config;
 enum { FID_GATE_ACCEPT = 0, FID_GATE_NO_FACE = 1, FID_GATE_LOW_CONFIDENCE = 2, FID_GATE_SIDE_FACE = 3, FID_GATE_LOW_QUALITY = 4 };
 /* det [B,cap,5], kps [B,cap,10], counts [B] as fid_scrfd_postprocess writes them; the first min(counts[b], faces_per_frame) slots
- * of frame b are faces.  pose (optional, may be NULL): [B, faces_per_frame, 2] yaw / pitch in radians, 0 = not available (then the
+ * of frame b are faces.  pose (optional, may be NULL): FLOAT64 [B, faces_per_frame, 2] yaw / pitch in radians (the reference hands python floats to
+ * math.degrees, :1226-1240: float32 here would move the verdict of an angle at the threshold), 0 = not available (then the
  * bbox analysis decides, as in the reference).  Outputs (device): quality [B, faces_per_frame, 5] = overall, blur, pose, lighting,
  * size (zeros in empty slots); side [B, faces_per_frame] = analyze_bbox_for_side_face's score | is_side_face << 16; best [B, 2] =
  * index of the FIRST face with the highest det_score (-1: no face) and its verdict (FID_GATE_*), checked in the reference's
  * order: confidence_threshold, side face, min_quality_threshold. */
 int fid_face_gates(fid_ctx *ctx, const float *det_dev, const float *kps_dev, const int32_t *counts_dev, int B, int cap,
-                   int faces_per_frame, const float *pose_dev, const fid_gate_config *cfg, float *quality_dev,
+                   int faces_per_frame, const double *pose_dev, const fid_gate_config *cfg, float *quality_dev,
                    int32_t *side_dev, int32_t *best_dev);
 
 /* ---- embeddings -> unit fp16 rows: the norm half of reference utils/helpers.py:120-123 ------ */
 int fid_l2_normalize_f16(fid_ctx *ctx, const float *emb_dev, int n, int dim, void *out_f16_dev);
 /* the same for the n = B * faces_per_frame face slots of a batch: slot (b, f) with f >= counts[b] holds no face (reference
- * main.py:132 iterates detected faces only) and is written as an all-zero row, which scores 0 against every gallery row and so
- * never matches (fid_match: idx -1, score 0).  The unit-embedding matrix thereby carries the face counts: after the all-gather of
- * SURVEY.md 8e every rank can tell another rank's faces from its empty slots (zero row <=> no face). */
+ * main.py:132 iterates detected faces only) and is written as a zero row, which scores 0 against every gallery row and so never
+ * matches (fid_match: idx -1, score 0).  Its FIRST element is -0.0 (fp16 bit pattern 0x8000), every other +0.0: the same numbers, but
+ * told apart from the all +0.0 row a degenerate embedding (zero / NaN / inf norm) of a DETECTED face gets.  The unit-embedding matrix
+ * thereby carries the face counts exactly: after the all-gather of SURVEY.md 8e every rank can tell another rank's faces from its
+ * empty slots (row == {-0.0, +0.0 ...} <=> no face; pipeline.gathered_face_counts). */
 int fid_l2_normalize_f16_slots(fid_ctx *ctx, const float *emb_dev, int n, int dim, const int32_t *counts_dev,
                                int faces_per_frame, void *out_f16_dev);
 

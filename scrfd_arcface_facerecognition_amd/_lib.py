@@ -165,7 +165,7 @@ def load():
                 fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol
                 fn.restype = res
                 fn.argtypes = args
-            if lib.fid_abi_version() != 1:
+            if lib.fid_abi_version() != 2:
                 raise RuntimeError("libfaceid ABI version mismatch")
             _lib = lib
     return _lib

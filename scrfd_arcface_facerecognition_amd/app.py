@@ -21,14 +21,14 @@ QUALITY_KEYS = ("overall", "blur", "pose", "lighting", "size")
 def face_gates(ctx, det_dev, kps_dev, counts_dev, batch: int, cap: int, faces_per_frame: int, config: Optional[GateConfig] = None, pose=None):
     """The reference's quality / side-face gates and best-face selection (smart_face_recognition.py:1145-1216, 1218-1297, 1299-1399,
     1473-1519) for every face of a batch, on the post-process's device arrays (`PostProcessor.det / .kps / .counts`, cap = their
-    second dimension).  pose: optional [batch, faces_per_frame, 2] yaw / pitch in radians (0 = not available).
+    second dimension).  pose: optional [batch, faces_per_frame, 2] yaw / pitch in radians (0 = not available), handed over as float64.
     -> quality [batch, F, 5] (QUALITY_KEYS), side score [batch, F], side flag [batch, F] (bool), best [batch, 2] = (face index or -1, verdict)"""
     cfg = config or GateConfig()
     F = faces_per_frame
     quality = ctx.empty((batch, F, 5), np.float32)
     side = ctx.empty((batch, F), np.int32)
     best = ctx.empty((batch, 2), np.int32)
-    pose_dev = ctx.to_device(np.ascontiguousarray(pose, dtype=np.float32).reshape(batch, F, 2)) if pose is not None else None
+    pose_dev = ctx.to_device(np.ascontiguousarray(pose, dtype=np.float64).reshape(batch, F, 2)) if pose is not None else None   # (float64 across the boundary: python floats in the reference)
     check(ctx.lib.fid_face_gates(ctx.handle, C.c_void_p(det_dev.ptr), C.c_void_p(kps_dev.ptr), C.c_void_p(counts_dev.ptr), batch, cap, F,
                                  C.c_void_p(pose_dev.ptr) if pose_dev is not None else None, C.byref(cfg), C.c_void_p(quality.ptr),
                                  C.c_void_p(side.ptr), C.c_void_p(best.ptr)))

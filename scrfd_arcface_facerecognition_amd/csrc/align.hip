@@ -205,6 +205,7 @@ int fid_align_crops(fid_ctx *ctx, const uint8_t *frames_dev, int B, int H, int W
     FID_REQUIRE(B > 0 && H > 0 && W > 0 && cap > 0 && faces_per_frame > 0, "bad sizes");
     FID_REQUIRE((long long)B * faces_per_frame <= 65535, "too many face slots per call (%lld)", (long long)B * faces_per_frame);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     dim3 grid(OUT / ROWS_PER_BLOCK, B * faces_per_frame);
     hipLaunchKernelGGL(align_warp, grid, dim3(256), 0, ctx->stream, frames_dev, H, W, kps_dev, counts_dev, cap,
                        faces_per_frame, crops_dev, M_dev);
@@ -224,6 +225,7 @@ int fid_letterbox(fid_ctx *ctx, const uint8_t *frames_dev, int B, int H, int W, 
     FID_REQUIRE(new_h > 0 && new_w > 0, "degenerate letterbox %dx%d", new_w, new_h);
     if (det_scale) *det_scale = (double)new_h / (double)H;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     dim3 grid(fid::cdiv(in_w, 256), in_h, B);
     const int area2x = (W == 2 * new_w && H == 2 * new_h) ? 1 : 0;
     static const bool lb_bytes = getenv("FID_LETTERBOX_BYTES") != nullptr;      // A/B: the one-pixel-per-thread kernel everywhere

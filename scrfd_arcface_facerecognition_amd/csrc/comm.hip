@@ -122,6 +122,7 @@ int fid_comm_info(fid_comm *comm, int *nranks, int *rank) {
 int fid_allgather(fid_ctx *ctx, fid_comm *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank) {
     FID_REQUIRE(ctx && comm && comm->comm && send_dev && recv_dev && bytes_per_rank > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     FID_RCCL(fid::g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, fid::DT_INT8, comm->comm, ctx->stream));
     return FID_OK;
 }

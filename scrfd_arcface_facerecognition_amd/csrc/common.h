@@ -81,8 +81,8 @@ struct fid_ctx {
     int num_cus = 256;
     std::mutex mu;
     // growable scratch arenas (never shrink; no allocation on the steady-state path)
-    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void *scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // 0 post-process, 1 split-K partials, 2 / 3 match, 4 the autotuner's cache-flush buffer
+    size_t scratch_bytes[5] = {0, 0, 0, 0, 0};
     hipEvent_t events[FID_MAX_EVENTS] = {};
     hipStream_t copy_stream = nullptr;   // H2D uploads that overlap compute (video front-end)
     hipEvent_t copy_done = nullptr, compute_done = nullptr;
@@ -97,6 +97,8 @@ struct fid_ctx {
 namespace fid {
 // scratch arena `slot` with at least `bytes` bytes (grows by reallocating; contents undefined)
 int get_scratch(fid_ctx *ctx, int slot, size_t bytes, void **out);
+// give a scratch arena back (synchronises the stream first): the autotuner's 320 MB flush buffer does not outlive a tuning run
+int release_scratch(fid_ctx *ctx, int slot);
 // hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for kernel `func` on the context's device.  The attribute is per device, so the
 // largest value set so far is remembered per (kernel, device) -- under a mutex: contexts on several devices and several host
 // threads launch the same kernels (a function-local static flag covered neither).

@@ -28,12 +28,24 @@ int get_scratch(fid_ctx *ctx, int slot, size_t bytes, void **out) {
     *out = ctx->scratch[slot];
     return FID_OK;
 }
+int release_scratch(fid_ctx *ctx, int slot) {
+    if (ctx->scratch[slot]) {
+        FID_HIP(hipStreamSynchronize(ctx->stream));
+        FID_HIP(hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr;
+        ctx->scratch_bytes[slot] = 0;
+    }
+    return FID_OK;
+}
+// hipFuncSetAttribute acts on the thread's CURRENT device: set the context's first, or a thread that drives contexts on two devices
+// records the attribute as done for one device while having set it on the other
 int ensure_dyn_lds(fid_ctx *ctx, const void *func, int bytes) {
     static std::mutex mu;
     static std::map<std::pair<const void *, int>, int> set_bytes;
     std::lock_guard<std::mutex> lk(mu);
     int &cur = set_bytes[std::make_pair(func, ctx->device)];
     if (bytes > cur) {
+        FID_HIP(hipSetDevice(ctx->device));
         FID_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         cur = bytes;
     }
@@ -181,6 +193,7 @@ static int ensure_copy_stream(fid_ctx *ctx) {
 int fid_upload_async(fid_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes) {
     FID_REQUIRE(ctx && dst_dev && src_pinned && bytes > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     FID_TRY(ensure_copy_stream(ctx));
     FID_HIP(hipEventRecord(ctx->compute_done, ctx->stream));
     FID_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->compute_done, 0));
@@ -193,6 +206,7 @@ int fid_upload_async(fid_ctx *ctx, void *dst_dev, const void *src_pinned, size_t
 int fid_upload_wait(fid_ctx *ctx) {
     FID_REQUIRE(ctx, "ctx is NULL");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     if (ctx->copy_done) FID_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_done, 0));
     return FID_OK;
 }
@@ -215,6 +229,7 @@ static int slot_events(fid_ctx *ctx, int slot) {
 int fid_upload_release(fid_ctx *ctx, int slot) {
     FID_REQUIRE(ctx, "ctx is NULL");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     FID_TRY(slot_events(ctx, slot));
     FID_HIP(hipEventRecord(ctx->slot_released[slot], ctx->stream));
     ctx->slot_has_release[slot] = true;
@@ -224,6 +239,7 @@ int fid_upload_release(fid_ctx *ctx, int slot) {
 int fid_upload_async_slot(fid_ctx *ctx, int slot, void *dst_dev, const void *src_pinned, size_t bytes) {
     FID_REQUIRE(ctx && dst_dev && src_pinned && bytes > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     FID_TRY(slot_events(ctx, slot));
     if (ctx->slot_has_release[slot]) FID_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->slot_released[slot], 0));
     FID_HIP(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
@@ -235,6 +251,7 @@ int fid_upload_async_slot(fid_ctx *ctx, int slot, void *dst_dev, const void *src
 int fid_upload_wait_slot(fid_ctx *ctx, int slot) {
     FID_REQUIRE(ctx, "ctx is NULL");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     FID_TRY(slot_events(ctx, slot));
     if (ctx->slot_has_upload[slot]) FID_HIP(hipStreamWaitEvent(ctx->stream, ctx->slot_uploaded[slot], 0));
     return FID_OK;

@@ -60,7 +60,7 @@ __device__ int bbox_side_score(const float *d, const fid_gate_config &c) {
 
 // one workgroup per frame, one thread per face slot; thread 0 then picks the frame's best face
 __global__ void __launch_bounds__(256) face_gates(const float *__restrict__ det, const float *__restrict__ kps, const int *__restrict__ counts,
-                                                  int cap, int F, const float *__restrict__ pose, const fid_gate_config c,
+                                                  int cap, int F, const double *__restrict__ pose, const fid_gate_config c,
                                                   float *__restrict__ quality, int *__restrict__ side, int *__restrict__ best) {
     const int b = blockIdx.x;
     const int n = min(counts[b], F);
@@ -73,8 +73,9 @@ __global__ void __launch_bounds__(256) face_gates(const float *__restrict__ det,
             const int score = bbox_side_score(d, c);
             bool flag = score >= c.decision_threshold;
             if (pose) {                                         // the angles decide whenever one of them is available (non-zero)
-                const double yaw = fabs((double)pose[((size_t)b * F + f) * 2] * (180.0 / 3.14159265358979323846));
-                const double pitch = fabs((double)pose[((size_t)b * F + f) * 2 + 1] * (180.0 / 3.14159265358979323846));
+                // math.degrees(x) = x * (180 / pi) in float64 (smart_face_recognition.py:1226-1240): the angles cross the boundary as float64
+                const double yaw = fabs(pose[((size_t)b * F + f) * 2] * (180.0 / 3.14159265358979323846));
+                const double pitch = fabs(pose[((size_t)b * F + f) * 2 + 1] * (180.0 / 3.14159265358979323846));
                 if (yaw > 0.0 || pitch > 0.0) flag = yaw > (double)c.yaw_threshold || pitch > (double)c.pitch_threshold;
             }
             sd = score | ((int)flag << 16);
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) face_gates(const float *__restrict__ det,
 using namespace fid;
 
 extern "C" int fid_face_gates(fid_ctx *ctx, const float *det_dev, const float *kps_dev, const int32_t *counts_dev, int B, int cap,
-                              int faces_per_frame, const float *pose_dev, const fid_gate_config *cfg, float *quality_dev, int32_t *side_dev,
+                              int faces_per_frame, const double *pose_dev, const fid_gate_config *cfg, float *quality_dev, int32_t *side_dev,
                               int32_t *best_dev) {
     FID_REQUIRE(ctx && det_dev && kps_dev && counts_dev && cfg && quality_dev && side_dev && best_dev, "NULL argument");
     FID_REQUIRE(B >= 0 && cap >= 1 && faces_per_frame >= 1 && faces_per_frame <= cap, "B=%d cap=%d faces_per_frame=%d", B, cap, faces_per_frame);

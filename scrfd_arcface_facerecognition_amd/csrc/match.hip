@@ -27,7 +27,11 @@ __global__ void __launch_bounds__(256) l2norm_rows(const float *__restrict__ x, 
     if (counts) {
         const int b = row / F, f = row - b * F;
         if (f >= counts[b]) {
-            for (int i = lane; i < dim; i += 64) out[(size_t)row * dim + i] = (_Float16)0.f;
+            // an EMPTY slot is a zero row whose first element is -0.0 (bit pattern 0x8000): numerically the zero row it always was (score 0,
+            // never a match), but distinguishable from the all +0.0 row a DEGENERATE face of the valid prefix gets below -- so the
+            // gathered matrix carries counts[] exactly (pipeline.gathered_face_counts; reference main.py:132 iterates every detected face)
+            for (int i = lane; i < dim; i += 64)
+                out[(size_t)row * dim + i] = i == 0 ? __builtin_bit_cast(_Float16, (unsigned short)0x8000) : (_Float16)0.f;
             return;
         }
     }
@@ -162,6 +166,7 @@ extern "C" {
 int fid_l2_normalize_f16(fid_ctx *ctx, const float *emb_dev, int n, int dim, void *out_f16_dev) {
     FID_REQUIRE(ctx && emb_dev && out_f16_dev && n > 0 && dim > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     hipLaunchKernelGGL(fid::l2norm_rows, dim3(fid::cdiv(n, 4)), dim3(256), 0, ctx->stream, emb_dev, n, dim, (_Float16 *)out_f16_dev, (const int *)nullptr, 1);
     FID_HIP(hipGetLastError());
     return FID_OK;
@@ -171,6 +176,7 @@ int fid_l2_normalize_f16_slots(fid_ctx *ctx, const float *emb_dev, int n, int di
                                void *out_f16_dev) {
     FID_REQUIRE(ctx && emb_dev && out_f16_dev && counts_dev && n > 0 && dim > 0 && faces_per_frame > 0 && n % faces_per_frame == 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     hipLaunchKernelGGL(fid::l2norm_rows, dim3(fid::cdiv(n, 4)), dim3(256), 0, ctx->stream, emb_dev, n, dim, (_Float16 *)out_f16_dev,
                        (const int *)counts_dev, faces_per_frame);
     FID_HIP(hipGetLastError());
@@ -222,6 +228,7 @@ int fid_gallery_data(fid_gallery *g, void **unit_rows_dev) {
 int fid_match(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, float thresh, int32_t *idx_dev, float *score_dev) {
     FID_REQUIRE(ctx && g && query_f16_dev && idx_dev && score_dev && n > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     void *ws;
     FID_TRY(fid::get_scratch(ctx, 2, (size_t)n * 8, &ws));
     FID_HIP(hipMemsetAsync(ws, 0, (size_t)n * 8, ctx->stream));
@@ -240,6 +247,7 @@ int fid_match_keys(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int 
     FID_REQUIRE(ctx && g && query_f16_dev && keys_dev && n > 0 && first_row >= 0, "bad args");
     FID_REQUIRE((long long)first_row + g->Gp < 0x7FFFFFFFll, "global gallery index overflows 31 bits");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     FID_HIP(hipMemsetAsync(keys_dev, 0, (size_t)n * 8, ctx->stream));
     return fid::gemm_vs_gallery(ctx, g, query_f16_dev, n, fid::CF_ARGMAX, nullptr, (unsigned long long *)keys_dev, first_row);
 }
@@ -248,6 +256,7 @@ int fid_match_merge(fid_ctx *ctx, const uint64_t *keys_dev, int parts, int n, in
                     float *score_dev) {
     FID_REQUIRE(ctx && keys_dev && idx_dev && score_dev && parts > 0 && n > 0 && G_total > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     hipLaunchKernelGGL(fid::match_finalize, dim3(fid::cdiv(n, 256)), dim3(256), 0, ctx->stream, (const unsigned long long *)keys_dev, parts, n,
                        G_total, thresh, idx_dev, score_dev);
     FID_HIP(hipGetLastError());
@@ -261,6 +270,7 @@ int fid_gallery_topk(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, in
     FID_REQUIRE(ctx && g && query_f16_dev && idx_dev && score_dev && n > 0, "bad args");
     FID_REQUIRE(k == 1 || k == 2 || k == 4 || k == 5 || k == 8, "k must be one of 1, 2, 4, 5, 8");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     // the score matrix is materialised per chunk of queries (<= 256 MiB) -- top-k needs every score once
     const int chunk = std::max(1, (int)std::min<long long>(n, (256ll << 20) / ((long long)g->Gp * 4)));
     void *ws;
@@ -286,6 +296,7 @@ int fid_gallery_set_rows(fid_ctx *ctx, fid_gallery *g, const int32_t *rows_host,
     FID_REQUIRE(ctx && g && rows_host && emb_host && n > 0, "bad args");
     for (int i = 0; i < n; i++) FID_REQUIRE(rows_host[i] >= 0 && rows_host[i] < g->G, "row %d outside the gallery (%d rows)", rows_host[i], g->G);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     void *ws;
     const size_t eb = (size_t)n * g->dim * 4, rb = ((size_t)n * 4 + 255) & ~(size_t)255;
     FID_TRY(fid::get_scratch(ctx, 3, eb + rb, &ws));
@@ -300,6 +311,7 @@ int fid_gallery_set_rows(fid_ctx *ctx, fid_gallery *g, const int32_t *rows_host,
 int fid_cosine_matrix(fid_ctx *ctx, fid_gallery *g, const void *query_f16_dev, int n, float *out_dev) {
     FID_REQUIRE(ctx && g && query_f16_dev && out_dev && n > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     return fid::gemm_vs_gallery(ctx, g, query_f16_dev, n, fid::CF_OUT_F32, out_dev, nullptr);
 }
 

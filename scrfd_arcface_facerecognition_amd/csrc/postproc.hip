@@ -318,6 +318,7 @@ int fid_scrfd_set_candidate_capacity(fid_ctx *ctx, int cand_cap) {
     // LDS of nms_select: ~9 bytes per candidate; 16800 anchors -> 151 KB of the CU's 160 KB
     FID_REQUIRE(cand_cap >= 16 && cand_cap <= 16800, "cand_cap %d outside [16, 16800]", cand_cap);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     ctx->cand_cap = cand_cap;
     FID_TRY(fid::ensure_dyn_lds(ctx, (const void *)nms_select, (int)fid::nms_lds_bytes(cand_cap, nullptr)));
     return FID_OK;
@@ -341,6 +342,7 @@ int fid_scrfd_postprocess(fid_ctx *ctx, const float *const head_dev[9], const in
         hv.batch_stride[k] = batch_stride[k];
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     FID_TRY(fid::ensure_dyn_lds(ctx, (const void *)nms_select, (int)fid::nms_lds_bytes(ctx->cand_cap, nullptr)));   // (above 64 KB from ~2000 candidates on)
     return fid::scrfd_postprocess_launch(ctx, hv, B, in_h, in_w, num_anchors, img_h, img_w, conf_thres, iou_thres, max_num,
                                          metric, det_dev, kps_dev, counts_dev, cap);
@@ -360,6 +362,7 @@ int fid_scrfd_decode(fid_ctx *ctx, const float *const head_dev[9], const int32_t
         hv.ptr[k] = head_dev[k]; hv.pix_stride[k] = pix_stride[k]; hv.anc_stride[k] = anc_stride[k]; hv.batch_stride[k] = batch_stride[k];
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     const int cc = ctx->cand_cap;
     const size_t off_keys = ((size_t)B * 4 + 255) & ~(size_t)255, off_data = off_keys + (size_t)B * cc * 8;
     void *ws;
@@ -381,6 +384,7 @@ int fid_scrfd_decode(fid_ctx *ctx, const float *const head_dev[9], const int32_t
 int fid_distance2bbox(fid_ctx *ctx, const float *points_dev, const float *dist_dev, int n, float *out_dev) {
     FID_REQUIRE(ctx && points_dev && dist_dev && out_dev && n > 0, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     hipLaunchKernelGGL(decode_points, dim3(fid::cdiv(n * 4, 256)), dim3(256), 0, ctx->stream, points_dev, dist_dev, n, 4, out_dev);
     FID_HIP(hipGetLastError());
     return FID_OK;
@@ -388,6 +392,7 @@ int fid_distance2bbox(fid_ctx *ctx, const float *points_dev, const float *dist_d
 int fid_distance2kps(fid_ctx *ctx, const float *points_dev, const float *dist_dev, int n, int ncol, float *out_dev) {
     FID_REQUIRE(ctx && points_dev && dist_dev && out_dev && n > 0 && ncol > 0 && ncol % 2 == 0 && ncol != 4, "bad args");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     hipLaunchKernelGGL(decode_points, dim3(fid::cdiv(n * ncol, 256)), dim3(256), 0, ctx->stream, points_dev, dist_dev, n, ncol, out_dev);
     FID_HIP(hipGetLastError());
     return FID_OK;
@@ -417,6 +422,7 @@ int fid_nms(fid_ctx *ctx, const float *dets_dev, int K, float iou_thres, int32_t
     FID_REQUIRE(ctx && keep_dev && count_dev && K >= 0, "bad args");
     FID_REQUIRE(K <= 16800, "K=%d exceeds 16800", K);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    FID_HIP(hipSetDevice(ctx->device));            // (a thread may drive contexts on several devices)
     if (K == 0) { FID_HIP(hipMemsetAsync(count_dev, 0, 4, ctx->stream)); return FID_OK; }
     FID_REQUIRE(dets_dev, "dets is NULL");
     const int cc = K;

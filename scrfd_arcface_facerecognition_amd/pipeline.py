@@ -74,8 +74,8 @@ class FacePipeline:
                                            self.post.cap, self.F, C.c_void_p(self.crops.ptr), None))
         self.rec.run_device(self.crops, self.n_slots)
         emb_ptr, _, _ = self.rec.tensor(self.rec.low.outputs[0])
-        # empty face slots (f >= counts[b]) become all-zero unit rows: they never match, and the matrix the all-gather moves tells
-        # every rank which slots of the other ranks hold faces (gathered_face_counts)
+        # empty face slots (f >= counts[b]) become zero rows marked by -0.0 in element 0: they never match, and the matrix the all-gather
+        # moves tells every rank which slots of the other ranks hold faces (gathered_face_counts)
         check(self.ctx.lib.fid_l2_normalize_f16_slots(self.ctx.handle, C.c_void_p(emb_ptr), self.n_slots, self.emb_dim,
                                                       C.c_void_p(self.post.counts.ptr), self.F, _lib._ptr(self.q)))
 
@@ -293,12 +293,26 @@ class Communicator:
             self.handle = None
 
 
+EMPTY_SLOT_MARK = 0x8000          # fp16 -0.0 in element 0 of an otherwise all +0.0 row (csrc/match.hip l2norm_rows)
+
+
+def empty_slot_rows(q_all: np.ndarray) -> np.ndarray:
+    """bool per row of a unit-embedding matrix (fp16, host copy): True = the row is the EMPTY-slot marker fid_l2_normalize_f16_slots writes
+    for face slots f >= counts[b] (-0.0 then +0.0s).  A degenerate face inside a frame's valid prefix (zero / NaN / inf embedding) is an
+    all +0.0 row instead: numerically the same zero row (never matches), but still a face."""
+    u = np.ascontiguousarray(np.asarray(q_all)).view(np.uint16).reshape(-1, np.asarray(q_all).shape[-1])
+    return (u[:, 0] == EMPTY_SLOT_MARK) & ~u[:, 1:].any(axis=1)
+
+
 def gathered_face_counts(q_all: np.ndarray, frames_total: int, faces_per_frame: int) -> np.ndarray:
-    """Face count of every frame of the WHOLE batch from the gathered unit-embedding matrix [frames_total * F, 512] (host copy):
-    a slot holds a face iff its row is not all zero (fid_l2_normalize_f16_slots), slots fill from f = 0 -- so the one collective of
-    SURVEY.md 8e also carries `counts[]` and idx_all / score_all can be read like the reference's per-face loop (main.py:132)."""
-    valid = (np.asarray(q_all).reshape(frames_total, faces_per_frame, -1) != 0).any(axis=2)
-    return valid.sum(axis=1).astype(np.int32)
+    """Face count of every frame of the WHOLE batch from the gathered unit-embedding matrix [frames_total * F, 512] (fp16 host copy):
+    a slot holds a face iff its row is not the empty-slot marker (empty_slot_rows) -- so the one collective of SURVEY.md 8e also carries
+    `counts[]` EXACTLY and idx_all / score_all can be read like the reference's per-face loop (main.py:132-134), which visits a detected
+    face whether or not its embedding is degenerate.  (Round 3 counted non-zero rows: a degenerate face at slot f < count shifted every
+    later slot of its frame by one.)"""
+    q = np.asarray(q_all)
+    assert q.dtype == np.float16, "the gathered matrix is fp16 (bit patterns matter: -0.0 marks an empty slot)"
+    return (~empty_slot_rows(q)).reshape(frames_total, faces_per_frame).sum(axis=1).astype(np.int32)
 
 
 def _slice_ptr(buf, row0: int, row_bytes: int):

@@ -18,7 +18,7 @@ import numpy as np
 from scrfd_arcface_facerecognition_amd import _lib
 lib = _lib.load()
 assert _lib.LIB_PATH.endswith("libfaceid_asan.so")
-assert lib.fid_abi_version() == 1
+assert lib.fid_abi_version() == 2
 n = C.c_int(-1)
 rc = lib.fid_device_count(C.byref(n))
 have_gpu = rc == 0 and n.value > 0

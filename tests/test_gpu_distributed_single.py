@@ -122,6 +122,29 @@ def test_empty_face_slots_travel_as_zero_rows():
     valid = np.array([f < counts[b] for b in range(B) for f in range(F)])
     assert np.array_equal(qs[valid], qp[valid]) and (qs[~valid] == 0).all() and (np.abs(qs[valid]).max(axis=1) > 0).all()
     assert np.array_equal(gathered_face_counts(qs, B, F), np.minimum(counts, F))
+    # an empty slot is {-0.0, +0.0 ...}: the same numbers as a zero row, another bit pattern than a DEGENERATE face's row (below)
+    assert (qs[~valid].view(np.uint16)[:, 0] == 0x8000).all() and not qs[~valid].view(np.uint16)[:, 1:].any()
+    # degenerate embeddings INSIDE a valid prefix (reference main.py:132-134 visits every detected face): an all-zero
+    # embedding at slot 0 of the 3-face frame 2 and a NaN one at the last valid slot of frame 3 become all +0.0 rows -- "Unknown", but
+    # COUNTED, so the faces behind them keep their slots on every rank
+    emb2 = emb.copy()
+    emb2[2 * F + 0] = 0
+    emb2[3 * F + 1, 7] = np.nan
+    gal_host2 = gal_host.copy()
+    gal_host2[11] = emb[2 * F + 1]                                      # the face BEHIND the degenerate slot matches row 11
+    gal2 = Gallery(ctx, gal_host2)
+    e2 = ctx.to_device(emb2)
+    check(ctx.lib.fid_l2_normalize_f16_slots(ctx.handle, C.c_void_p(e2.ptr), B * F, 512, C.c_void_p(c_dev.ptr), F, C.c_void_p(q.ptr)))
+    ctx.sync()
+    q2 = q.download()
+    assert not q2[2 * F].view(np.uint16).any() and not q2[3 * F + 1].view(np.uint16).any()
+    assert np.array_equal(gathered_face_counts(q2, B, F), np.minimum(counts, F))
+    idx2, score2 = ctx.empty((B * F,), np.int32), ctx.empty((B * F,), np.float32)
+    gal2.match_device(q, B * F, 0.05, idx2, score2)
+    ctx.sync()
+    i2 = idx2.download()
+    assert i2[2 * F] == -1 and i2[3 * F + 1] == -1 and i2[2 * F + 1] == 11
+    check(ctx.lib.fid_l2_normalize_f16_slots(ctx.handle, C.c_void_p(e_dev.ptr), B * F, 512, C.c_void_p(c_dev.ptr), F, C.c_void_p(q.ptr)))
     idx, score = ctx.empty((B * F,), np.int32), ctx.empty((B * F,), np.float32)
     gal.match_device(q, B * F, 0.05, idx, score)
     ctx.sync()

@@ -48,6 +48,32 @@ def test_gates_equal_the_reference_vectors(ctx):
         assert (int(best[b, 0]), int(best[b, 1])) == (idx, verdict), b
 
 
+def test_pose_angles_at_the_threshold_in_float64(ctx):
+    """the reference hands python floats (float64 radians) to math.degrees (smart_face_recognition.py:1226-1240); the angles cross
+    the C-ABI as float64 too, so an angle a few ulps either side of the 35-degree threshold gets the reference's verdict -- in float32
+    radians(35) rounds to 34.9999998 and radians(36) to 36.000001 degrees, i.e. the verdict of an angle AT the threshold would depend on
+    which way float32 rounds it."""
+    import math
+    cfg = ogates.DEFAULT_CONFIG
+    thr = float(cfg["yaw_threshold"])
+    base = math.radians(thr)
+    angles, up, dn = [base], base, base
+    for _ in range(39):                                      # +-1 .. +-39 ulps of float64 around the threshold (float32 cannot tell them apart)
+        up, dn = float(np.nextafter(up, 1.0)), float(np.nextafter(dn, 0.0))
+        angles += [up, dn]
+    angles += [-a for a in angles[:9]] + [float(np.float32(base)), float(np.nextafter(np.float32(base), np.float32(1)))]
+    n = len(angles)
+    det = np.tile(np.array([100, 100, 220, 260, 0.9], np.float32), (1, n, 1))
+    kps = np.tile(np.array([[130, 150], [190, 150], [160, 190], [140, 220], [180, 220]], np.float32), (1, n, 1, 1))
+    for col in (0, 1):                                       # yaw, then pitch
+        pose = np.zeros((1, n, 2), np.float64)
+        pose[0, :, col] = angles
+        _, _, flag, _ = run(ctx, det, kps, np.array([n]), n, pose=pose)
+        want = [ogates.is_side_face(det[0, i, :4], 0.9, *(pose[0, i]), cfg) for i in range(n)]
+        assert flag.reshape(-1).tolist() == [bool(w) for w in want], col
+        assert any(want) and not all(want)                   # the sweep really straddles the threshold
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_gates_on_ragged_batches(ctx, seed):
     """counts of 0 .. cap faces per frame, more detections than face slots (cap > F), ties of the top score, custom thresholds"""

@@ -283,3 +283,54 @@ def test_arcface_r50_chunk500_vs_oracle(ctx):
         ref = onets.run_net(net, P, oalign.blob_from_images([crops[i]], net.in_scale, net.in_mean))[net.outputs[0]].reshape(-1)
         assert 1 - float(ref @ e[i] / np.linalg.norm(ref) / np.linalg.norm(e[i])) < 1e-3, i
         assert np.abs(ref / np.linalg.norm(ref) - e[i] / np.linalg.norm(e[i])).max() < 1e-3, i
+
+
+@pytest.mark.parametrize("arch,hw", [("scrfd_10g", (320, 320)), ("scrfd_2.5g", (320, 320)), ("scrfd_500m", (320, 320)),
+                                     ("arcface_r50", (112, 112)), ("arcface_mbf", (112, 112))])
+def test_truncated_blob_is_refused(ctx, arch, hw, monkeypatch):
+    """every blob region a kernel builds a buffer resource from is bounds-checked by fid_net_create (second weight image of the
+    shortcut-absorbing convs, both filter banks of the fused residual blocks incl. the two-chunk 64-channel image, the bottleneck's w1 /
+    b1 / s1 / depthwise tables, the depthwise + pointwise op's tables, the fused stem's six regions, bias / slope rows of plain convs):
+    a blob that ENDS at the start of any region an op names is refused with FID_E_INVALID instead of being read past on the GPU."""
+    import ctypes as C
+    from scrfd_arcface_facerecognition_amd import _lib
+    from scrfd_arcface_facerecognition_amd._lib import FaceIdError, check
+    from scrfd_arcface_facerecognition_amd.lower import (OP_BBLOCK, OP_CONV, OP_DWPW, OP_MBBLOCK, OP_STEMFUSED, lower)
+    if arch == "scrfd_500m":
+        monkeypatch.setenv("FID_DWPW_FUSE", "1")             # so that the table holds OP_DWPW records too
+    net = archs.ARCHS[arch](hw)
+    low = lower(net, archs.synth_params(net, 0))
+    ops = np.ascontiguousarray(low.ops, dtype=np.int32)
+    tens = np.ascontiguousarray(low.tensors, dtype=np.int32)
+
+    def create(nbytes):
+        h = C.c_void_p()
+        check(ctx.lib.fid_net_create(ctx.handle, ops.ctypes.data_as(_lib.c_i32_p), ops.shape[0], tens.ctypes.data_as(_lib.c_i32_p),
+                                     tens.shape[0], low.blob, nbytes, net.in_hw[0], net.in_hw[1], 1, C.byref(h)))
+        return h
+    h = create(len(low.blob))                                # the complete blob is accepted
+    check(ctx.lib.fid_net_destroy(ctx.handle, h))
+    words = {OP_STEMFUSED: (20, 21, 22, 23, 24, 25), OP_BBLOCK: (20, 21, 22, 23, 24), OP_DWPW: (20, 21, 22), OP_MBBLOCK: (20, 21, 22, 24, 25, 28)}
+    cuts, kinds = set(), set()
+    for op in ops:
+        t = int(op[0])
+        ws = (13, 15, 16) + words.get(t, ()) + ((29, 30) if t == OP_CONV and op[23] > 0 else ())
+        for w in ws:
+            if op[w] > 0:
+                cuts.add(int(op[w])); kinds.add((t, w))
+    assert len(cuts) > 10
+    if arch == "arcface_r50":
+        assert (OP_CONV, 29) in kinds and (OP_BBLOCK, 22) in kinds
+    if arch == "arcface_mbf":
+        assert (OP_MBBLOCK, 20) in kinds and (OP_MBBLOCK, 28) in kinds
+    if arch == "scrfd_500m":
+        assert (OP_DWPW, 20) in kinds
+    for cut in sorted(cuts):
+        with pytest.raises(FaceIdError):
+            create(cut)
+    # the two-chunk image of a 64-channel fused block: a blob that holds only its FIRST chunk (the 73 728 bytes round 3 checked) is refused
+    for op in ops:
+        if int(op[0]) == OP_BBLOCK and int(tens[op[1]][1]) == 64:
+            with pytest.raises(FaceIdError):
+                create(max(int(op[20]), int(op[22])) + 73728)
+            break
