@@ -825,9 +825,14 @@ static std::vector<ConvPlan> conv_candidates_all(const ConvArgs &a, int num_cus,
 std::vector<ConvPlan> conv_candidates(const ConvArgs &a, int num_cus, bool allow_split) {
     std::vector<ConvPlan> all = conv_candidates_all(a, num_cus, allow_split);
     if (!a.in2) return all;
-    std::vector<ConvPlan> only;                      // fused shortcut (extra K-steps on a second tensor): the LDS-DMA implicit GEMM only
+    std::vector<ConvPlan> only;                      // fused shortcut (extra K-steps on a second tensor): the LDS-DMA implicit GEMM ...
     for (const ConvPlan &c : all)
         if (c.gen == 2 && a.Cin2_p % c.bk == 0) only.push_back(c);
+    if (conv_s2_applicable(a)) {                     // ... and the parity-plane stride-2 kernel with the shortcut as one more step per item (ns = 10)
+        ConvPlan d{};
+        d.gen = 10; d.ksplit = 1; d.bm = 128; d.bn = a.Cout_p; d.bk = 32; d.ns = 10;
+        only.push_back(d);
+    }
     return only;
 }
 
@@ -939,7 +944,7 @@ static std::vector<ConvPlan> conv_candidates_all(const ConvArgs &a, int num_cus,
 int plan_alt_kind(const ConvPlan &plan) {
     static const bool pc2_packed = getenv("FID_PC2_PLAIN") == nullptr;
     if (plan.gen == 8) return pc2_packed ? 1 : 0;
-    if (plan.gen == 9 || plan.gen == 10) return 2;
+    if (plan.gen == 9 || plan.gen == 10 || (plan.gen == 12 && plan.ns == 10)) return 2;
     if (plan.gen == 11) return 3;
     return 0;
 }

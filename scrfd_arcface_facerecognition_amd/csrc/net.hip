@@ -421,7 +421,7 @@ TensorView view(const fid_net *net, int id, int first = 0) {
 }
 
 // bump when conv_candidates() / the kernels' tile meanings change: it is hashed into the plan key
-constexpr int FID_PLAN_REV = 3;
+constexpr int FID_PLAN_REV = 4;
 
 unsigned long long fnv1a(const void *p, size_t n, unsigned long long h = 1469598103934665603ull) {
     const unsigned char *b = (const unsigned char *)p;
@@ -596,13 +596,14 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 std::vector<ConvPlan> v = conv_candidates(a, ctx->num_cus, true);
                 static const bool no_sc = getenv("FID_NO_SC_RUNTIME") != nullptr;
                 if (has_sc && !no_sc)
-                    for (ConvPlan c : conv_candidates(af, ctx->num_cus, true)) { c.gen = 12; v.push_back(c); }
+                    for (ConvPlan c : conv_candidates(af, ctx->num_cus, true)) { c.gen = 12; v.push_back(c); }   // (ns = 10: conv3x3_s2's form, else generation 2's)
                 return v;
             };
             auto launch_plan = [&](const ConvPlan &c) -> int {
                 if (c.gen != 12) return conv_launch(ctx, a, c);
                 ConvPlan c2 = c;
-                c2.gen = 2;
+                c2.gen = c.ns == 10 ? 10 : 2;
+                af.w_alt = a.w_alt;                              // (the 3x3 part in fragment order: set_alt_weights built it from the plain first image)
                 return conv_launch(ctx, af, c2);
             };
             ConvPlan plan;
@@ -638,7 +639,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 if (const char *fn = getenv("FID_FORCE_NS")) {       // tests: one ring variant of generation 2 / 5
                     std::vector<ConvPlan> only;
                     for (const ConvPlan &c : cands)
-                        if (((c.gen == 2 || c.gen == 5) && c.ns == atoi(fn)) || (c.gen == 9 && (c.ns == 1 ? 3 : (c.ns == 4 ? 4 : (c.ns == 6 ? (c.bm == 512 ? 7 : 6) : c.bm / 256))) == atoi(fn))) only.push_back(c);
+                        if (((c.gen == 2 || c.gen == 5 || c.gen == 12) && c.ns == atoi(fn)) || (c.gen == 9 && (c.ns == 1 ? 3 : (c.ns == 4 ? 4 : (c.ns == 6 ? (c.bm == 512 ? 7 : 6) : c.bm / 256))) == atoi(fn))) only.push_back(c);
                     if (!only.empty()) cands = only;
                 }
                 const float pc2_bias = getenv("FID_PC2_BIAS") ? (float)atof(getenv("FID_PC2_BIAS")) : 1.f;

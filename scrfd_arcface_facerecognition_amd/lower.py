@@ -80,31 +80,52 @@ class Lowered:
         self.fused_groups: Dict[str, list] = {}   # fused op name -> graph nodes it covers
 
 
-def _shortcut_target(net, i, tensors, tid, shp):
-    """node i = a residual block's shortcut conv (1x1, stride s, + BN, no activation) whose only consumer is the residual add of a later
-    3x3 conv of the same output shape that the implicit-GEMM kernel can extend by K-steps on the block input: that conv node, or None"""
+def _dual_ok(net, i, tensors, tid, shp):
+    """nodes i, i+1 = an "avg_down" shortcut conv and the block's 3x3 / stride-2 conv1 on the same input, in the shapes csrc/conv_s2.hip's DUAL
+    variant takes (64 stored input channels, 96 padded couts each): lowered as ONE op with two outputs"""
+    import os
     n = net.nodes[i]
-    if not (n.k == 1 and n.pad == 0 and n.stride in (1, 2) and n.act == "none" and n.res is None and not n.pre_bn and not n.pre_avgpool
-            and not n.res_up2 and n.src != "input" and n.name not in net.outputs):
+    nxt = net.nodes[i + 1] if i + 1 < len(net.nodes) else None
+    return (n.kind == "conv" and n.groups == 1 and n.pre_avgpool and not os.environ.get("FID_NO_DOWN_FUSE")
+            and nxt is not None and nxt.kind == "conv" and nxt.groups == 1 and nxt.src == n.src and nxt.k == 3 and nxt.stride == 2
+            and nxt.pad == 1 and nxt.res is None and not nxt.pre_bn and not n.pre_bn and not nxt.pre_avgpool
+            and nxt.act in ("none", "relu") and n.act == "none" and n.res is None and not n.res_up2 and not nxt.res_up2
+            and tensors[tid[n.src]][1] == 64 and _rup(n.cout, CPAD) == 96 and _rup(nxt.cout, CPAD) == 96
+            and shp[n.name][1:] == shp[nxt.name][1:])
+
+
+def _shortcut_target(net, i, tensors, tid, shp):
+    """node i = a residual block's shortcut conv whose only consumer is the residual add of a later 3x3 conv of the same output shape that the
+    implicit-GEMM kernel can extend by K-steps on the block input: that conv node, or None.  Two forms:
+      * IResNet: 1x1 / stride s + BN feeding the block's stride-s conv2 (one extra tap at (s oy, s ox));
+      * ResNetV1e "avg_down" (SCRFD): 2x2 average pool + 1x1 + BN = a 2x2 / stride-2 conv feeding the block's stride-1 conv2 (four extra taps at
+        (2 oy + {0,1}, 2 ox + {0,1})) -- unless csrc/conv_s2.hip's DUAL launch already computes it beside conv1 (_dual_ok)."""
+    n = net.nodes[i]
+    if not (n.k == 1 and n.pad == 0 and n.act == "none" and n.res is None and not n.pre_bn and not n.res_up2 and n.src != "input"
+            and n.name not in net.outputs and n.groups == 1):
         return None
+    avg = bool(n.pre_avgpool)
+    if (avg and n.stride != 1) or (not avg and n.stride not in (1, 2)) or (avg and _dual_ok(net, i, tensors, tid, shp)):
+        return None
+    s_eff, taps = (2, 2) if avg else (n.stride, 1)
     users = [x for x in net.nodes if getattr(x, "src", None) == n.name or getattr(x, "res", None) == n.name]
     if len(users) != 1:
         return None
     m = users[0]
-    if not (m.kind == "conv" and m.res == n.name and m.src != n.name and m.groups == 1 and m.k == 3 and m.pad == 1 and m.stride == 2 and not m.pre_bn
-            and not m.pre_avgpool and not m.res_up2 and net.nodes.index(m) > i and shp[m.name] == shp[n.name]):
+    if not (m.kind == "conv" and m.res == n.name and m.src != n.name and m.groups == 1 and m.k == 3 and m.pad == 1 and not m.pre_bn
+            and m.stride == (1 if avg else 2) and not m.pre_avgpool and not m.res_up2 and net.nodes.index(m) > i and shp[m.name] == shp[n.name]):
         return None
-    x_t, y_t = tensors[tid[n.src]], None
+    x_t = tensors[tid[n.src]]
     if m.src not in tid:                                  # (conv2's input is lowered after the shortcut: its padded width is its own cout rounded up)
         src_node = next(x for x in net.nodes if x.name == m.src)
         cin_p = _rup(src_node.cout, CPAD)
     else:
         cin_p = tensors[tid[m.src]][1]
-    # the sampled pixel (oy * s, ox * s) must exist, the channel counts must suit a 32- or 64-wide K-step of the LDS-DMA implicit GEMM
+    # every sampled pixel (oy * s + dy, ox * s + dx) must exist, the channel counts must suit a 32- or 64-wide K-step of the LDS-DMA implicit GEMM
     _, ho, wo = shp[m.name]
-    if x_t[4] != 0 or x_t[1] % 32 or cin_p % 32 or (ho - 1) * n.stride >= x_t[2] or (wo - 1) * n.stride >= x_t[3]:
+    if x_t[4] != 0 or x_t[1] % 32 or cin_p % 32 or (ho - 1) * s_eff + taps - 1 >= x_t[2] or (wo - 1) * s_eff + taps - 1 >= x_t[3]:
         return None
-    if n.stride != m.stride:
+    if not avg and n.stride != m.stride:
         return None
     return m
 
@@ -322,12 +343,7 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             dst = new_tensor(n.name, cout, ho, wo)
             emit(n.name, type=OP_STEM, src=-1, dst=dst, kh=3, kw=3, stride=n.stride, pad=1, cin=3, cout=cout,
                  act=ACT[n.act], woff=woff, wbytes=wbytes, boff=boff, soff=soff, wrows=cp)
-        elif (n.kind == "conv" and n.groups == 1 and n.pre_avgpool and not os.environ.get("FID_NO_DOWN_FUSE")
-              and nxt is not None and nxt.kind == "conv" and nxt.groups == 1 and nxt.src == n.src and nxt.k == 3 and nxt.stride == 2
-              and nxt.pad == 1 and nxt.res is None and not nxt.pre_bn and not n.pre_bn and not nxt.pre_avgpool
-              and nxt.act in ("none", "relu") and n.act == "none" and n.res is None and not n.res_up2 and not nxt.res_up2
-              and tensors[tid[n.src]][1] == 64 and _rup(n.cout, CPAD) == 96 and _rup(nxt.cout, CPAD) == 96
-              and shp[n.name][1:] == shp[nxt.name][1:]):
+        elif _dual_ok(net, ni_, tensors, tid, shp):
             # The block's shortcut (2x2 average pool + 1x1 conv + BN = a 2x2 / stride-2 conv with W/4) reads the tensor the block's
             # first conv (3x3 / stride 2 / pad 1) reads, and its window is taps (1..2, 1..2) of that conv's window: ONE launch of the
             # stride-2 kernel with twice the couts and two outputs fetches the (large) input once instead of twice (csrc/conv_s2.hip,
@@ -471,6 +487,8 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             boff, _ = blob.add(bt)
             if sc is not None:                                        # second image: weight rows [9 * Cin_p | Cin2_p], one bias row = both biases
                 Wsc, bsc = folded(sc)
+                if sc.pre_avgpool:                                    # average pool + 1x1 = a 2x2 / stride-2 kernel with W / 4: four taps (dy2, dx2)
+                    Wsc = np.repeat(np.repeat(Wsc, 2, axis=2), 2, axis=3) / 4.0
                 x_t = tensors[tid[sc.src]]
                 assert ncls == 1 and ops[sc_op][2] == tid[sc.name]
                 W2p = np.concatenate([Wp.reshape(cout_p, -1), pack_weights(Wsc, x_t[1], cout_p).reshape(cout_p, -1)], axis=1)
@@ -486,7 +504,8 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
                  wbytes=wbytes, boff=boff, soff=soff, wrows=cout_p)
             if sc is not None:                                        # csrc/net.h W_X_SRC2 ..: block input, taps, row length, stride, second images, the shortcut's op
                 r = ops[-1]
-                r[23], r[24], r[25], r[28], r[29], r[30], r[31] = tid[sc.src] + 1, 1, 1, sc.stride, w2off, b2off, sc_op + 1
+                t2, kw2, s2 = (4, 2, 2) if sc.pre_avgpool else (1, 1, sc.stride)
+                r[23], r[24], r[25], r[28], r[29], r[30], r[31] = tid[sc.src] + 1, t2, kw2, s2, w2off, b2off, sc_op + 1
                 ops[sc_op][29] = len(ops)                             # the shortcut op knows the conv that may absorb it (index + 1)
         elif n.kind == "conv":                                        # depthwise
             assert n.groups == n.cin == n.cout and not n.pre_bn and not n.pre_avgpool and n.res is None

@@ -118,3 +118,47 @@ def test_random_absorbed_shortcut(ctx, monkeypatch, seed):
     ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["b.conv2"], (0, 2, 3, 1))
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3, (hw, cin, cout, batch, picks["b.conv2"])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FID_FUZZ_SEEDS", "8"))))
+def test_random_absorbed_avg_down_shortcut(ctx, monkeypatch, seed):
+    """SCRFD's downsampling BasicBlock (ResNetV1e "avg_down": 2x2 average pool + 1x1 conv + BN shortcut, conv1 3x3 / stride 2, conv2 3x3 / stride 1
+    + shortcut, ReLU) with the shortcut forced onto conv2's K axis as FOUR extra taps on the block input (generation 12, round 4), and the same
+    block with the shortcut as its own op (fresh autotune without generation 12): both against the fp32 oracle.  Even map sizes only: on an odd
+    map conv1 (stride 2, pad 1) yields ceil(H / 2) rows and the average pool floor(H / 2), which is not a valid block."""
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    rng = np.random.default_rng(6500 + seed)
+    hw = (2 * int(rng.integers(4, 45)), 2 * int(rng.integers(4, 45)))
+    cin = int(rng.choice([88, 96, 128, 48, 224]))                 # (64 stored input channels + 96 couts would take the DUAL launch instead)
+    cout = int(rng.choice([88, 224, 128, 80, 256]))
+    batch = int(rng.integers(1, 6))
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 32, act="relu"))
+    net.add(Conv("x", "s", 32, cin, k=1, pad=0, act="relu"))
+    net.add(Conv("b.down", "x", cin, cout, k=1, stride=1, pad=0, pre_avgpool=True))
+    net.add(Conv("b.conv1", "x", cin, cout, stride=2, act="relu"))
+    net.add(Conv("b.conv2", "b.conv1", cout, cout, act="relu", res="b.down"))
+    net.outputs = ["b.conv2"]
+    P = archs.synth_params(net, seed=300 + seed)
+    images = rng.integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["b.conv2"], (0, 2, 3, 1))
+    cp = lambda c: (c + 31) // 32 * 32
+    for force in ("12", None):
+        if force:
+            monkeypatch.setenv("FID_FORCE_GEN", force)
+        else:
+            monkeypatch.delenv("FID_FORCE_GEN")
+            monkeypatch.setenv("FID_NO_SC_FUSE", "1")             # (lower.py: no second weight image, the shortcut stays an op of its own)
+        cn = CompiledNet(ctx, net, P, max_batch=batch)
+        for _ in range(2):
+            cn.run(images)
+        got = cn.read("b.conv2", batch)
+        picks = {p["name"]: (p["gen"], p["ksplit"]) for p in cn.plans()}
+        cn.close()
+        bk = 64 if cp(cout) % 64 == 0 else 32
+        if force:
+            assert (picks["b.conv2"][0] == 12) == (cp(cin) % bk == 0), (picks, cin, cout)
+        else:
+            assert picks["b.conv2"][0] != 12
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3, (hw, cin, cout, batch, force, picks["b.conv2"])

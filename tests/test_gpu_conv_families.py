@@ -141,10 +141,11 @@ def test_dethead_family(ctx, monkeypatch, gen, hw, cin, batch):
 
 
 # stride-2 3x3 convs (generation 10: parity-plane patches, resident weights) against the implicit-GEMM families and the oracle:
-# 64 / 96-channel inputs, 64 / 96 / 128 couts, with and without a residual (the IResNet block's downsample branch), odd maps
+# 64 / 96 / 128-channel inputs, 64 / 96 / 128 couts, with and without a residual (the IResNet block's downsample branch), odd maps
 @pytest.mark.parametrize("gen", [1, 2, 10, 11])
 @pytest.mark.parametrize("hw,cin,cout,res,batch", [((64, 96), 64, 64, True, 3), ((37, 45), 64, 96, False, 2), ((80, 80), 88, 88, False, 2),
-                                                   ((56, 56), 64, 128, True, 5), ((30, 18), 96, 64, True, 3)])
+                                                   ((56, 56), 64, 128, True, 5), ((30, 18), 96, 64, True, 3),
+                                                   ((56, 56), 128, 128, True, 5), ((45, 38), 128, 128, False, 2), ((16, 16), 128, 128, True, 1)])   # (round 4: 128 input channels)
 def test_stride2_family(ctx, monkeypatch, gen, hw, cin, cout, res, batch):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     monkeypatch.setenv("FID_FORCE_GEN", str(gen))
@@ -327,15 +328,23 @@ def test_fused_bottleneck(ctx, monkeypatch, fuse, hw, cin, g, cout, stride, res,
 # (lower.py keeps both forms in the table, the autotuner decides per batch size; conv.hip generation 2 with a second input tensor = a generation-12
 # pick of conv2, the shortcut op is then skipped).  "fused": generation 12 forced; "tuned": whatever the tuner picks; "plain": the lowering without
 # the second weight image -- all against the oracle: IResNet-50's four shapes scaled down, odd maps, channel counts whose K-step must be 32 wide
-@pytest.mark.parametrize("mode", ["fused", "tuned", "plain"])
-@pytest.mark.parametrize("hw,cin,cout,batch", [((56, 56), 64, 64, 2), ((28, 28), 64, 128, 3), ((37, 45), 64, 96, 2), ((14, 14), 256, 512, 5), ((30, 22), 88, 160, 1)])
+# "fused_s2" (round 4): the same form inside the parity-plane stride-2 kernel (conv_s2.hip NX = 2: one more step per item on the 8 x 16 sampled
+# pixels of the block input; a generation-12 pick with ns = 10) -- 64 -> 64 and 128 -> 128 channels with a 64-channel block input, tile-multiple
+# and ragged maps (Ho / Wo not multiples of 8 / 16)
+@pytest.mark.parametrize("mode", ["fused", "fused_s2", "tuned", "plain"])
+@pytest.mark.parametrize("hw,cin,cout,batch", [((56, 56), 64, 64, 2), ((28, 28), 64, 128, 3), ((37, 45), 64, 96, 2), ((14, 14), 256, 512, 5), ((30, 22), 88, 160, 1),
+                                               ((44, 70), 64, 64, 3), ((20, 36), 64, 128, 2), ((112, 112), 64, 64, 1), ((64, 32), 64, 128, 5)])
 def test_fused_shortcut_conv(ctx, monkeypatch, mode, hw, cin, cout, batch):
     from scrfd_arcface_facerecognition_amd import lower
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     if mode == "plain":
         monkeypatch.setenv("FID_NO_SC_FUSE", "1")
-    if mode == "fused":
+    if mode in ("fused", "fused_s2"):
         monkeypatch.setenv("FID_FORCE_GEN", "12")            # (only conv2 has generation-12 candidates: every other op tunes as usual)
+    if mode == "fused_s2":
+        if not (cin == 64 and cout in (64, 128) and (hw[0] + 1) // 2 >= 8 and (hw[1] + 1) // 2 >= 8):
+            pytest.skip("conv3x3_s2's shortcut-absorbing form takes 64 -> 64 and 128 -> 128 channels with a 64-channel block input")
+        monkeypatch.setenv("FID_FORCE_NS", "10")
     net = Net("t", hw, 127.5, 1.0 / 128.0)
     net.add(Conv("s", "input", 3, 64, act="prelu"))
     x = "s"
@@ -355,9 +364,12 @@ def test_fused_shortcut_conv(ctx, monkeypatch, mode, hw, cin, cout, batch):
         cn.run(images)
     got = cn.read("b.conv2", batch)
     picks = {p["name"]: p["gen"] for p in cn.plans()}
+    ns = {p["name"]: p["ns"] for p in cn.plans()}
     cn.close()
-    if mode == "fused":
+    if mode in ("fused", "fused_s2"):
         assert picks["b.conv2"] == 12
+    if mode == "fused_s2":
+        assert ns["b.conv2"] == 10
     if mode == "plain":
         assert picks["b.conv2"] != 12
     ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["b.conv2"], (0, 2, 3, 1))
