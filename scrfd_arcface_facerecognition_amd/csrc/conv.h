@@ -124,6 +124,12 @@ bool dwpw_applicable(int Gp, int Cout_p);
 int dwpw_launch(fid_ctx *ctx, const void *in, const float *dw_w, const float *dw_b, const float *dw_s, int dw_act, const void *pw_w, const float *pw_b,
                 const float *pw_s, int pw_act, const void *res, void *out, int B, int H, int W, int Ho, int Wo, int Gp, int Cout_p, int stride);
 
+// stem_block.hip: IResNet's first two convs (u8 crop -> conv3x3 3 -> 64 + PReLU -> [BN] conv3x3 64 -> 64 + PReLU) in one launch; the first conv's
+// result leaves only at the even pixels (compact second output for the block's stride-2 shortcut)
+bool stem_block_applicable(int H, int W);
+int stem_block_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const float *w0, const float *b0, const float *s0, int act0, const void *w1,
+                      const float *b1, int ncls1, const float *s1, int act1, void *out, void *xe);
+
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,
                       const float *b1, const void *w2, const float *b2, void *out, int C2p);

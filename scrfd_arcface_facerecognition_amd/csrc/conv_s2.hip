@@ -59,10 +59,10 @@ struct S2Args {
     FastDiv d_tpi, d_tx;
     unsigned in_bytes, out_bytes, w_bytes;
     // NX > 0: the block's 1x1 / stride-2 shortcut conv rides along (IResNet's downsampling block; lower.py, the generation-12 form of this
-    // kernel): x = the block input [B, H2, W2, NX*32] read at (2 oy, 2 ox), its weights = columns [9 Cin_p, 9 Cin_p + NX*32) of the plain
+    // kernel): x = the block input [B, H2, W2, NX*32] read at (xs oy, xs ox), its weights = columns [9 Cin_p, 9 Cin_p + NX*32) of the plain
     // second weight image w2 (rows of `krow` halfs), the bias table is the two convs' summed bias -- no residual read
     const void *in2, *w2;
-    int H2, W2, krow;
+    int H2, W2, krow, xs;     // xs: x is sampled at (xs oy, xs ox): 2 = the block input itself, 1 = its even-pixel copy (stem_block.hip)
     unsigned in2_bytes, w2_bytes;
 };
 
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(NW * 64, DUAL ? 3 : ((NCH * NW >= 32 || NSLOT 
                 const bool in = real && c.n >= 0 && oy < a.Ho && ox < a.Wo;
                 // (every surplus piece gets an offset of its own: the compiler folds two loads with identical operands into one -- found by
                 //  tools/check_waitcnt.py, the step then issued MAX_P - 1 operations and the counted waits were one short)
-                const unsigned vo = in ? (unsigned)((((c.n * a.H2 + 2 * oy) * a.W2 + 2 * ox) * (NX * CK) + (jr >> 3) * CK + (((lane & 3) ^ swz64(lin)) * 8)) * 2) : OOB - (unsigned)k * 16u;
+                const unsigned vo = in ? (unsigned)((((c.n * a.H2 + a.xs * oy) * a.W2 + a.xs * ox) * (NX * CK) + (jr >> 3) * CK + (((lane & 3) ^ swz64(lin)) * 8)) * 2) : OOB - (unsigned)k * 16u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
             }
             return;
@@ -423,7 +423,7 @@ static bool conv_s2_dual_ok(const ConvArgs &a) {
 // the shortcut-absorbing form (lower.py's second weight image; a generation-12 pick with ns = 10): IResNet's downsampling block on 64 -> 64 and
 // 128 -> 128 channels whose block input has 64 channels (layer1.0 / layer2.0 of IResNet-50)
 static bool conv_s2_sc_ok(const ConvArgs &a) {
-    return a.in2 != nullptr && a.T2 == 1 && a.s2 == 2 && a.Cin2_p == 64 && a.res == nullptr && a.H2 > (a.Ho - 1) * 2 && a.W2 > (a.Wo - 1) * 2 &&
+    return a.in2 != nullptr && a.T2 == 1 && (a.s2 == 2 || a.s2 == 1) && a.Cin2_p == 64 && a.res == nullptr && a.H2 > (a.Ho - 1) * a.s2 && a.W2 > (a.Wo - 1) * a.s2 &&
            ((a.Cin_p == 64 && a.Cout_p == 64) || (a.Cin_p == 128 && a.Cout_p == 128));
 }
 
@@ -471,7 +471,7 @@ int conv_s2_launch(fid_ctx *ctx, const ConvArgs &c) {
     a.w_bytes = (unsigned)repack_bytes(2, c.w_rows, c.Cin_p);
     if (c.out2) return s2_launch_t<12, 2, true>(ctx, a);
     if (c.in2) {                                                // the shortcut rides along: plain second image for its fragments, summed bias
-        a.in2 = c.in2; a.w2 = c.w; a.H2 = c.H2; a.W2 = c.W2; a.krow = 9 * c.Cin_p + c.T2 * c.Cin2_p;
+        a.in2 = c.in2; a.w2 = c.w; a.H2 = c.H2; a.W2 = c.W2; a.krow = 9 * c.Cin_p + c.T2 * c.Cin2_p; a.xs = c.s2;
         a.in2_bytes = c.in2_bytes; a.w2_bytes = c.w_bytes;
         FID_REQUIRE(c.w_bytes >= (unsigned)((size_t)c.w_rows * a.krow * 2), "conv3x3_s2: second weight image of %u bytes for %d rows of %d halfs", c.w_bytes, c.w_rows, a.krow);
         if (c.Cin_p == 64) return s2_launch_t<4, 2, false, 2, 2>(ctx, a);

@@ -4,7 +4,7 @@
 
 namespace fid {
 
-enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6, OP_DWPW = 7, OP_MBBLOCK = 8 };
+enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6, OP_DWPW = 7, OP_MBBLOCK = 8, OP_STEMBLOCK = 9 };
 
 // int32 word indices inside one op record (FID_OP_WORDS = 32 words)
 enum : int {
@@ -41,6 +41,12 @@ enum : int {
     // stride; the first pointwise conv's fp16 weights [Gp][Cin_p] / fp32 bias / slopes / activation, the depthwise fp32 tables [9][Gp] / bias /
     // slopes / activation and the padded expanded width Gp; W_F_MACS_* = the MACs of the three layers
     W_M_W1 = 20, W_M_B1 = 21, W_M_S1 = 22, W_M_ACT1 = 23, W_M_DW = 24, W_M_DWB = 25, W_M_DWS = 28, W_M_DWACT = 29, W_M_GP = 30,
+    // OP_STEMBLOCK (stem_block.hip; lower.py): the recogniser's first conv (uint8 frame -> 64 channels; W_WOFF / W_BOFF / W_SOFF = its fp32 [64][27]
+    // weights, bias, PReLU slopes or -1) + the 3x3 / stride-1 conv on 64 channels that consumes it, in one launch: the second conv's repack-kind-2
+    // image, bias rows (W_FLAGS & CF_BORDER: 9 border classes), PReLU slopes or -1, the FIRST conv's activation, and the tensor id + 1 of the
+    // compact second output (the first conv's result at the even pixels, for the block's stride-2 shortcut; 0: none).  W_ACT = the second conv's
+    // activation, W_DST its output, W_F_MACS_* = the MACs of both
+    W_S_W1 = 20, W_S_B1 = 21, W_S_S1 = 22, W_S_ACT0 = 23, W_S_DST2 = 24,
     // OP_CONV fused with the block's shortcut (lower.py; conv_s2.hip DUAL): second output's tensor id + 1 (0: plain conv), its activation,
     // padded couts of the first output; W_F_MACS_LO then holds the shortcut's MACs per image
     W_X_DST2 = 20, W_X_ACT2 = 21, W_X_COUT1P = 22,

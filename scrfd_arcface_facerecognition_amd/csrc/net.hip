@@ -743,6 +743,19 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                                       (const float *)(blob + op[W_F_B2]), dst.ptr, dst.Cp));
             break;
         }
+        case OP_STEMBLOCK: {
+            FID_REQUIRE(dst.Cp == 64 && dst.dtype == 0 && dst.H == net->in_h && dst.W == net->in_w && stem_block_applicable(dst.H, dst.W), "op %d: bad fused stem-block record", oi);
+            void *xe = nullptr;
+            if (op[W_S_DST2] > 0) {
+                const TensorView d2 = view(net, op[W_S_DST2] - 1, first);
+                FID_REQUIRE(d2.Cp == 64 && d2.dtype == 0 && d2.H == (dst.H + 1) / 2 && d2.W == (dst.W + 1) / 2, "op %d: second output of the fused stem block", oi);
+                xe = d2.ptr;
+            }
+            FID_TRY(stem_block_launch(ctx, images, batch, dst.H, dst.W, (const float *)(blob + op[W_WOFF]), bias, slope, op[W_S_ACT0], blob + op[W_S_W1],
+                                      (const float *)(blob + op[W_S_B1]), (op[W_FLAGS] & CF_BORDER) ? 9 : 1,
+                                      op[W_S_S1] >= 0 ? (const float *)(blob + op[W_S_S1]) : nullptr, op[W_ACT], dst.ptr, xe));
+            break;
+        }
         case OP_BBLOCK: {
             const TensorView src = view(net, op[W_SRC], first);
             FID_REQUIRE((src.Cp == 64 || src.Cp == 32) && dst.Cp == src.Cp && src.H == dst.H && src.W == dst.W && src.dtype == 0 && dst.dtype == 0, "op %d: bad fused block record", oi);
@@ -974,7 +987,7 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
         auto opt_in_blob = [&](long long off, size_t bytes) { return off < 0 || (size_t)off + bytes <= blob_bytes; };
         bool ok = op[W_DST] >= 0 && op[W_DST] < n_tensors && op[W_SRC] >= -1 && op[W_SRC] < n_tensors && op[W_RES] >= -1 && op[W_RES] < n_tensors &&
                   op[W_WOFF] >= -1 && opt_in_blob(op[W_WOFF], (size_t)std::max(0, op[W_WBYTES])) &&
-                  (op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_STEMFUSED) == (op[W_SRC] == -1) && op[W_WROWS] >= 0;
+                  (op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_STEMBLOCK) == (op[W_SRC] == -1) && op[W_WROWS] >= 0;
         if (ok) {
             const int cp_src = op[W_SRC] >= 0 ? net->tensors[(size_t)op[W_SRC] * FID_TENSOR_WORDS + T_CP] : 0;
             const int cp_dst = net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS + T_CP];
@@ -999,6 +1012,13 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
             case OP_STEM:
             case OP_DWCONV:
                 ok = opt_in_blob(op[W_BOFF], rows * 4) && opt_in_blob(op[W_SOFF], rows * 4);
+                break;
+            case OP_STEMBLOCK:
+                ok = cp_dst == 64 && op[W_WOFF] >= 0 && (size_t)op[W_WBYTES] >= 64 * 27 * 4 && in_blob(op[W_BOFF], 64 * 4) && opt_in_blob(op[W_SOFF], 64 * 4) &&
+                     in_blob(op[W_S_W1], (size_t)2 * 73728) && in_blob(op[W_S_B1], (size_t)((op[W_FLAGS] & CF_BORDER) ? 9 : 1) * 64 * 4) &&
+                     opt_in_blob(op[W_S_S1], 64 * 4) && (op[W_S_ACT0] == ACT_RELU || (op[W_S_ACT0] == ACT_PRELU && op[W_SOFF] >= 0)) &&
+                     (op[W_ACT] == ACT_RELU || (op[W_ACT] == ACT_PRELU && op[W_S_S1] >= 0)) && op[W_S_DST2] >= 0 && op[W_S_DST2] <= n_tensors &&
+                     (op[W_S_DST2] == 0 || net->tensors[(size_t)(op[W_S_DST2] - 1) * FID_TENSOR_WORDS + T_CP] == 64);
                 break;
             case OP_STEMFUSED:
                 ok = in_blob(op[W_F_W0], 32 * 32 * 2) && in_blob(op[W_F_B0], 32 * 4) && in_blob(op[W_F_W1], (size_t)32 * 9 * 32 * 2) && in_blob(op[W_F_B1], 32 * 4) &&
@@ -1032,7 +1052,7 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
             return FID_E_INVALID;
         }
         const int32_t *dt = &net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS];
-        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK || op[W_TYPE] == OP_DWPW || op[W_TYPE] == OP_MBBLOCK)
+        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK || op[W_TYPE] == OP_DWPW || op[W_TYPE] == OP_MBBLOCK || op[W_TYPE] == OP_STEMBLOCK)
             net->macs_per_image += (double)(((unsigned long long)(unsigned)op[W_F_MACS_HI] << 32) | (unsigned)op[W_F_MACS_LO]);
         if (op[W_TYPE] == OP_CONV && op[W_X_DST2] > 0) net->macs_per_image += (double)(unsigned)op[W_F_MACS_LO];   // the fused shortcut's share
         if (op[W_TYPE] == OP_CONV || op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_DWCONV)

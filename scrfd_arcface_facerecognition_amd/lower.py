@@ -15,6 +15,9 @@ models/scrfd.py:59-62, models/arcface.py:18-21), written down:
   * the three SCRFD output convs of a level become one conv with 2+8+20 output channels, sigmoid on
     the first two, bbox scale folded in, fp32 output;
   * blobFromImage's (x-127.5)*scale and BGR->RGB swap are folded into the first conv's weights;
+  * IResNet's first conv (3 -> 64, stride 1) and the 3x3 conv on 64 channels that consumes it become ONE op (csrc/stem_block.hip): the first
+    conv's map only exists in LDS; the block's 1x1 / stride-2 shortcut reads a compact copy of it at the even pixels (FID_NO_STEMBLOCK_FUSE=1
+    keeps the two convs apart);
   * FC consumes the NHWC activation directly (weight columns permuted from CHW order).
 
 Weights are packed fp16 [Cout_p][tap][Cin_p] (channels padded to multiples of 32 with zeros), all
@@ -30,7 +33,7 @@ import numpy as np
 from .archs import BN_EPS, Net, infer_shapes
 
 OP_WORDS, TENSOR_WORDS = 32, 8
-OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK = 1, 2, 3, 4, 5, 6, 7, 8
+OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK, OP_STEMBLOCK = 1, 2, 3, 4, 5, 6, 7, 8, 9
 ACT = {"none": 0, "relu": 1, "prelu": 2}
 CF_RES_UP2, CF_BORDER, CF_OUT_F32 = 1, 2, 4
 CPAD = 32
@@ -125,7 +128,7 @@ def _shortcut_target(net, i, tensors, tid, shp):
     _, ho, wo = shp[m.name]
     if x_t[4] != 0 or x_t[1] % 32 or cin_p % 32 or (ho - 1) * s_eff + taps - 1 >= x_t[2] or (wo - 1) * s_eff + taps - 1 >= x_t[3]:
         return None
-    if not avg and n.stride != m.stride:
+    if not avg and n.stride != m.stride and not getattr(n, "_even_src", False):   # (_even_src: the shortcut reads the fused stem block's even-pixel copy of x with stride 1)
         return None
     return m
 
@@ -309,6 +312,67 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
         fused_upto = 4
 
     skip = set()
+    # ---- IResNet's stem + the first 3x3 conv on its result: one fused op (csrc/stem_block.hip) ----
+    if fused_upto == 0 and not os.environ.get("FID_NO_STEMBLOCK_FUSE") and len(nd) >= 2:
+        st = nd[0]
+        users = [(i, x) for i, x in enumerate(nd) if getattr(x, "src", None) == st.name or getattr(x, "res", None) == st.name]
+        c1s = [(i, x) for i, x in users if x.kind == "conv" and x.src == st.name and x.k == 3 and x.stride == 1 and x.pad == 1 and x.groups == 1
+               and x.cin == 64 and x.cout == 64 and x.res is None and x.act in ("relu", "prelu") and not x.pre_avgpool and not x.res_up2]
+        others = [(i, x) for i, x in users if not c1s or x is not c1s[0][1]]
+        sc_ok = all(x.kind == "conv" and x.src == st.name and x.res != st.name and x.k == 1 and x.stride == 2 and x.pad == 0 and x.groups == 1
+                    and not x.pre_bn and not x.pre_avgpool for _, x in others)
+        H0, W0 = net.in_hw
+        if (st.kind == "conv" and st.src == "input" and st.k == 3 and st.stride == 1 and st.pad == 1 and st.groups == 1 and st.cout == 64
+                and st.act in ("relu", "prelu") and st.res is None and not st.pre_bn and len(c1s) == 1 and sc_ok and len(others) <= 1
+                and st.name not in net.outputs and W0 % 4 == 0 and H0 >= 3 and abs(net.in_mean - 127.5) < 1e-12):
+            import copy
+            import dataclasses
+            ci, c1 = c1s[0]
+            W = P[st.wname + ".weight"].astype(np.float64)               # [64, 3(RGB), 3, 3]
+            b = P[st.wname + ".bias"].astype(np.float64) if st.bias else np.zeros(64)
+            if st.post_bn:
+                a2, b2 = _bn_affine(P, st.wname + ".post_bn")
+                W = W * a2[:, None, None, None]
+                b = b * a2 + b2
+            Wd = np.ascontiguousarray((W[:, ::-1] * (net.in_scale / 2.0)).transpose(0, 2, 3, 1), dtype=np.float32)   # [co][dy][dx][c_bgr]: the kernel's input is 2 p - 255
+            w0off, w0bytes = blob.add(Wd)
+            b0off = blob.add(padded(b, 64))[0]
+            s0off = blob.add(padded(P[st.wname + ".prelu"], 64))[0] if st.act == "prelu" else -1
+            W1, bt1, _, _ = fold_conv(c1, (H0, W0))
+            b1t = np.zeros((bt1.shape[0], 64), dtype=np.float32)
+            b1t[:, :64] = bt1
+            w1off = blob.add(repack_kind2(pack_weights(W1, 64, 64)))[0]
+            b1off = blob.add(b1t)[0]
+            s1off = blob.add(padded(P[c1.wname + ".prelu"], 64))[0] if c1.act == "prelu" else -1
+            dst = new_tensor(c1.name, 64, H0, W0)
+            dst2 = 0
+            if others:                                                  # the block's stride-2 shortcut reads x at the even pixels only: a compact second output
+                even = st.name + ".even"
+                dst2 = new_tensor(even, 64, (H0 + 1) // 2, (W0 + 1) // 2) + 1
+                shp[even] = (64, (H0 + 1) // 2, (W0 + 1) // 2)
+                oi_, sc_node = others[0]
+                sc2 = dataclasses.replace(sc_node, src=even, stride=1)
+                sc2._even_src = True
+                net = copy.copy(net)
+                net.nodes = list(nd)
+                net.nodes[oi_] = sc2
+                nd = net.nodes
+            rec = [0] * OP_WORDS
+            rec[0], rec[1], rec[2], rec[3] = OP_STEMBLOCK, -1, dst, -1
+            rec[4] = rec[5] = 3
+            rec[6], rec[7], rec[8], rec[9], rec[10] = 1, 1, 3, 64, ACT[c1.act]
+            rec[11] = CF_BORDER if bt1.shape[0] == 9 else 0
+            rec[13], rec[14], rec[15], rec[16], rec[17], rec[18] = w0off, w0bytes, b0off, s0off, 64, 1
+            rec[20], rec[21], rec[22], rec[23], rec[24] = w1off, b1off, s1off, ACT[st.act], dst2
+            macs = H0 * W0 * 64 * 27 + H0 * W0 * 64 * 64 * 9
+            rec[26], rec[27] = macs & 0xFFFFFFFF, macs >> 32
+            if rec[26] >= 2 ** 31:
+                rec[26] -= 2 ** 32
+            ops.append(rec)
+            op_names.append(c1.name)
+            op_nodes.append([st.name, c1.name])
+            out.fused_groups[c1.name] = [st.name, c1.name]
+            skip.update({0, ci})
     pending_sc = {}                                   # conv2 name -> its block's shortcut conv node, fused as extra K-steps (below)
     for ni_, n in enumerate(net.nodes):
         if ni_ < fused_upto or ni_ in skip:
@@ -629,6 +693,8 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
 
     for oi, rec in enumerate(ops):
         dsts = [rec[2]] + ([rec[20] - 1] if rec[0] == OP_CONV and rec[20] > 0 else [])    # (a fused shortcut + conv op writes two tensors)
+        if rec[0] == OP_STEMBLOCK and rec[24] > 0:
+            dsts.append(rec[24] - 1)                                                      # (... and so does the fused stem block)
         for d in dsts:
             need = nbytes(d)
             if d in keep or not free:

@@ -375,3 +375,49 @@ def test_fused_shortcut_conv(ctx, monkeypatch, mode, hw, cin, cout, batch):
     ref = np.transpose(onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))["b.conv2"], (0, 2, 3, 1))
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3, picks
+
+
+# IResNet's stem + layer1.0.conv1 as one launch (csrc/stem_block.hip, round 4): the first conv's map never leaves the CU, the block's stride-2
+# shortcut reads a compact even-pixel copy of it.  Fused and unfused (FID_NO_STEMBLOCK_FUSE=1) lowering against the oracle: tile-multiple and
+# ragged maps (16 x 16 tiles), odd heights, with / without the BatchNorm in front of the second conv (9 / 1 bias rows), ReLU / PReLU, with and
+# without the shortcut consumer, and the whole downsampling block behind it (conv2 absorbing the shortcut from the even-pixel copy)
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("hw,pre_bn,act,block,batch", [((112, 112), True, "prelu", True, 2), ((48, 36), True, "prelu", True, 3), ((50, 44), False, "relu", True, 2),
+                                                       ((17, 20), True, "prelu", False, 1), ((33, 64), True, "relu", True, 5), ((16, 16), False, "prelu", True, 1)])
+def test_fused_stem_block(ctx, monkeypatch, fuse, hw, pre_bn, act, block, batch):
+    from scrfd_arcface_facerecognition_amd import lower
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    if not fuse:
+        monkeypatch.setenv("FID_NO_STEMBLOCK_FUSE", "1")
+    net = Net("t", hw, 127.5, 1.0 / 127.5)
+    net.add(Conv("stem", "input", 3, 64, act=act))
+    if block:
+        net.add(Conv("b.down", "stem", 64, 64, k=1, stride=2, pad=0))
+    net.add(Conv("b.conv1", "stem", 64, 64, act=act, pre_bn=pre_bn))
+    outs = ["b.conv1"]
+    if block:
+        net.add(Conv("b.conv2", "b.conv1", 64, 64, stride=2, res="b.down"))
+        outs.append("b.conv2")
+    net.outputs = outs
+    P = archs.synth_params(net, seed=71)
+    low = lower.lower(net, P)
+    assert (int(low.ops[0][0]) == lower.OP_STEMBLOCK) == fuse
+    if fuse:
+        assert ("stem.even" in low.tensor_id) == block and "stem" not in low.tensor_id
+    images = np.random.default_rng(15).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    for _ in range(2):
+        cn.run(images)
+    got = {o: cn.read(o, batch) for o in outs}
+    if block and fuse:                                        # the compact copy = the oracle's stem map at the even pixels
+        got["stem.even"] = cn.read("stem.even", batch)
+    cn.close()
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean), keep=["stem"])
+    for o in outs:
+        r = np.transpose(ref[o], (0, 2, 3, 1))
+        assert got[o].shape == r.shape
+        assert np.abs(got[o] - r).max() / np.abs(r).max() < 6e-3, (o, hw)
+    if "stem.even" in got:
+        r = np.transpose(ref["stem"], (0, 2, 3, 1))[:, ::2, ::2]
+        assert got["stem.even"].shape == r.shape
+        assert np.abs(got["stem.even"] - r).max() / np.abs(r).max() < 3e-3

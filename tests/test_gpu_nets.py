@@ -24,7 +24,7 @@ def run_both(ctx, net, P, images, names):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     cn = CompiledNet(ctx, net, P, max_batch=len(images))
     cn.run(images)
-    got = {k: cn.read(k, len(images)) for k in names}
+    got = {k: cn.read(k, len(images)) for k in names if k in cn.low.tensor_id}      # (a tensor that a fused op keeps on chip has no record)
     blob = align.blob_from_images(list(images), net.in_scale, net.in_mean)
     ref = onets.run_net(net, P, blob, keep=names)
     cn.close()
@@ -73,7 +73,8 @@ def test_layer_cases(ctx, case, hw, batch):
     rng = np.random.default_rng(7)
     images = rng.integers(0, 256, (batch, hw[0], hw[1], 3), dtype=np.uint8)
     got, ref = run_both(ctx, net, P, images, ["s", "c"])
-    assert rel_err(got["s"], ref["s"]) < 3e-3          # stem: exact inputs, fp32 math, fp16 store
+    if "s" in got:                                     # (3x3_s1_c64: the first conv and the 64 -> 64 conv behind it are one launch, csrc/stem_block.hip)
+        assert rel_err(got["s"], ref["s"]) < 3e-3      # stem: exact inputs, fp32 math, fp16 store
     assert rel_err(got["c"], ref["c"]) < 6e-3, case
 
 

@@ -16,7 +16,7 @@ import os
 import sys
 
 CONV = ("conv_mfma_kernel", "conv_mfma_dma_kernel", "conv3x3_direct", "conv3x3_chunked", "conv3x3_pp", "conv3x3_pc", "conv_mfma_pc_kernel", "conv3x3_wr", "conv3x3_s2", "conv_gw",
-        "scrfd_stem_fused", "stem_conv_mfma", "conv_bb", "conv3x3_ks", "scrfd_stem_rows", "dwpw_kernel", "mbf_block")
+        "scrfd_stem_fused", "stem_conv_mfma", "conv_bb", "conv3x3_ks", "scrfd_stem_rows", "dwpw_kernel", "mbf_block", "ir_stem_block")
 
 
 def total(run_dir, counter):
@@ -44,9 +44,9 @@ def main():
     launches = (n6 - n2) / 4
     hbm = 2 * fetch + write
     print(json.dumps({
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py "
-                  "--steps {2,6} --warmup 1 --streams 1; per-step = (6-step run - 2-step run)/4; MFMA conv kernel families only "
-                  "(tools/pmc_traffic.py)",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), "
+                  + (sys.argv[2] if len(sys.argv) > 2 else "python3 bench.py --steps {2,6} --warmup 1 --streams 1")
+                  + "; per-step = (6-step run - 2-step run)/4; MFMA conv kernel families only (tools/pmc_traffic.py)",
         "fetch_bytes_per_step_raw": fetch,
         "write_bytes_per_step": write,
         "fetch_correction": "gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) coalesced reads "
