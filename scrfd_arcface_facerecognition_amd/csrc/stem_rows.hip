@@ -66,6 +66,12 @@ __device__ __forceinline__ float row_shl(float x) {
 #ifndef STEM_WPS
 #define STEM_WPS 2
 #endif
+// -DSTEM_RELOAD_W1=1 (with -DSTEM_WPS=3 and FID_STEM_PY=6): conv1's nine weight fragments are re-read from global memory (L1 / L2 hits) after
+// every tile's write-out instead of living in registers through conv2 + pooling, the phase with the most live registers -- the 36 VGPRs that
+// kept twelve waves per CU from fitting under the 168-register cap without scratch (round 3: 68 B of scratch per lane, 665 -> 725 us)
+#ifndef STEM_RELOAD_W1
+#define STEM_RELOAD_W1 0
+#endif
 // (PY = 6 tiles need 50 KB of LDS: three workgroups fit a CU if the registers allow three waves per SIMD: -DSTEM_WPS=3 forces <= 168 VGPRs there)
 template <int C2P, int PY>
 __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(const StemRArgs a) {
@@ -354,6 +360,12 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
                 if (s < PY * PXT * CPP && gy < a.Hp && gx < a.Wp)
                     *(u32x4 *)((char *)a.out + (((size_t)n * a.Hp + gy) * a.Wp + gx) * ROWB2 + c * 16) = *(const u32x4 *)(smem + OFF_STG + pix * ROWB2 + c * 16);
             }
+        }
+        if (STEM_RELOAD_W1 && PY == 6) {                          // (the pointer is made opaque per tile: the loads must not be hoisted back out of the loop)
+            const _Float16 *wp = a.w1;
+            asm volatile("" : "+s"(wp));
+#pragma unroll
+            for (int t = 0; t < 9; t++) w1f[t] = *(const half8 *)(wp + ((f1 * 16 + frow) * 9 + t) * 32 + fq * 8);
         }
     }
 }
