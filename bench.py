@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec); ~6.3 TB/s is what a streaming copy achieves
-PROFILE_DIRS = ("r03", "r02", "r01")
+PROFILE_DIRS = ("r04", "r03", "r02", "r01")
 # persisted kernel plan (per conv op and batch size: kernel family / tile / split-K), keyed by device name and layer-table hash: with it
 # every box runs the same kernels and fp32 summation orders (bit-identical heads / embeddings) and nothing is timed at start-up.
 # The tracked file is loaded READ-ONLY (FID_PLAN_RO): picks missing from it are tuned as before but never written back by a bench
@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=512, help="frames of the CPU baseline sample (0 = skip; also skips the side legs)")
     ap.add_argument("--agree-frames", type=int, default=64, help="frames of the timed batch whose NMS survivors are compared with the fp32 oracle's (~0.1 s each)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-one-lane", action="store_true", help="skip the ms_per_step_1lane leg (profiling runs: the kernel statistics then hold the timed steps only)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the F = 8 and H2D-included side measurements")
     ap.add_argument("--comm", choices=("torch", "native"), default=os.environ.get("FID_COMM", "torch"),
                     help="who issues the all-gather at N > 1: torch.distributed (RCCL as backend nccl) or the C-ABI's fid_comm (RCCL)")
@@ -446,7 +447,7 @@ def main():
     log(f"timed regions done: {[round(r / args.steps * 1e3, 3) for r in repeats]} ms/step, median {elapsed / args.steps * 1e3:.3f}")
     # the same steps on ONE lane (VERDICT r3 item 5 / Weak 9): a kernel change that is slower alone but faster in the two-lane step stays visible
     one_lane_ms = None
-    if len(lanes) > 1:
+    if len(lanes) > 1 and not args.no_one_lane:
         def step_lane0(i):
             step(0)
         one = [timed_region(step_lane0, args.steps) for _ in range(3)]

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes2 -o k -- python3 $R/bench.py --steps 60 --warmup 3 --cpu-frames 0 --no-roofline --repeats 1 > $O/lanes2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes2 -o k -- python3 $R/bench.py --steps 60 --warmup 3 --cpu-frames 0 --no-roofline --repeats 1 --no-one-lane > $O/lanes2.log 2>&1
 echo "lanes2 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes1 -o k -- python3 $R/bench.py --steps 60 --warmup 3 --cpu-frames 0 --no-roofline --repeats 1 --streams 1 > $O/lanes1.log 2>&1
 echo "lanes1 done"
