@@ -270,6 +270,10 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default=os.environ.get("FID_BENCH_BACKEND", "nccl"),
                     help="gloo = REHEARSAL of the N > 1 code path with several ranks on ONE GPU (the gather is staged through host "
                          "memory; RCCL refuses two ranks on one device); its numbers mean nothing")
+    ap.add_argument("--schedule", choices=("lanes", "stages"), default=os.environ.get("FID_BENCH_SCHEDULE", "lanes"),
+                    help="how two batches are kept in flight per GPU: 'lanes' = two whole pipelines on two streams, steps issued round-robin; "
+                         "'stages' (experiment, N = 1) = ONE detector on stream A and ONE recogniser + gallery on stream B, step i+1's detect stage "
+                         "beside step i's align / embed / match stages (events between the streams, two sets of post-process buffers)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FID_BENCH_STREAMS", "2")),
                     help="pipelines in flight per GPU: steps are issued round-robin to this many independent "
                          "contexts/HIP streams so that the small kernels of one batch overlap another batch's")
@@ -401,6 +405,35 @@ def main():
             else:
                 ln.pipe.run_step(ln.frames_dev, 640, 640, ln.gallery, thresh)
 
+    if args.schedule == "stages" and world == 1:
+        # stage-pipelined schedule: the detector (net + post-process) lives on lane 0's context / stream, the recogniser and the gallery on a second
+        # context / stream; pipes[k] (k = i & 1) own the post-process buffers, crops and result buffers of the steps in flight
+        sA, cA = stream, ctx
+        sB = torch.cuda.Stream()
+        cB = Context(local_rank, sB.cuda_stream)
+        recB = CompiledNet(cB, rec_net, rec_P, max_batch=B * F)
+        galB = Gallery(cB, gal_host, names)
+        with torch.cuda.stream(sB):
+            spipes = [FacePipeline(cB, det, recB, batch=B, faces_per_frame=F) for _ in range(2)]
+        ev_det = [torch.cuda.Event() for _ in range(2)]
+        ev_free = [None, None]
+
+        def step(i):                                      # noqa: F811  (replaces the lane schedule)
+            k = i & 1
+            p = spipes[k]
+            with torch.cuda.stream(sA):
+                if ev_free[k] is not None:
+                    sA.wait_event(ev_free[k])             # the align stage of step i - 2 has read this pipe's post-process buffers
+                p.detect(frames_dev, 640, 640)
+                sA.record_event(ev_det[k])
+            with torch.cuda.stream(sB):
+                sB.wait_event(ev_det[k])
+                p.embed(frames_dev, 640, 640)
+                ev_free[k] = sB.record_event()
+                p.match(galB, thresh)
+        lanes = [lanes[0]]                                # (warm-up loop below: one pass per pipe)
+        pipe = spipes[0]
+
     enqueue_s = []
 
     def timed_region(fn, k):
@@ -430,7 +463,7 @@ def main():
     def picks_at(cn, n):
         return {p["op"] for p in cn.plans() if p["batch"] == n}
     pre_picks = {"det": picks_at(det, B), "rec": picks_at(rec, B * F)}
-    for i in range(len(lanes)):              # every lane tunes its kernels alone on the GPU
+    for i in range(2 if args.schedule == "stages" else len(lanes)):              # every lane tunes its kernels alone on the GPU
         step(i)
         torch.cuda.synchronize()
     post_picks = {"det": picks_at(det, B), "rec": picks_at(rec, B * F)}

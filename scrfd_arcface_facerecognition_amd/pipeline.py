@@ -40,7 +40,7 @@ class FacePipeline:
         self.B, self.F = int(batch), int(faces_per_frame)
         self.conf, self.iou, self.metric = float(conf_thres), float(iou_thres), int(metric)
         self.in_hw = det.in_hw
-        self.post = PostProcessor(ctx, batch, cap=det_cap)
+        self.post = PostProcessor(det.ctx, batch, cap=det_cap)     # (the detector may live on another context / stream than the recogniser: the whole detect stage runs there)
         self.n_slots = self.B * self.F
         self.crops = ctx.empty((self.n_slots, 112, 112, 3), np.uint8)
         self.emb_dim = 512
@@ -58,10 +58,10 @@ class FacePipeline:
             det_in = frames_dev
         else:
             if self._det_in is None:
-                self._det_in = self.ctx.empty((self.B, in_h, in_w, 3), np.uint8)
+                self._det_in = self.det.ctx.empty((self.B, in_h, in_w, 3), np.uint8)
             sc = C.c_double()
-            check(self.ctx.lib.fid_letterbox(self.ctx.handle, _lib._ptr(frames_dev), self.B, H, W,
-                                             C.c_void_p(self._det_in.ptr), in_h, in_w, C.byref(sc)))
+            check(self.det.ctx.lib.fid_letterbox(self.det.ctx.handle, _lib._ptr(frames_dev), self.B, H, W,
+                                                 C.c_void_p(self._det_in.ptr), in_h, in_w, C.byref(sc)))
             det_in = self._det_in
         self.det.run_device(det_in, self.B)
         if self._hv is None:
