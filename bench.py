@@ -112,6 +112,8 @@ def op_bytes(cn, oi, n):
         b += cp_src * gp * 2 + 9 * gp * 4
     elif int(op[0]) == 7:                                  # depthwise + pointwise (csrc/dwpw.hip): + the depthwise table
         b += 9 * cp_src * 4
+    elif int(op[0]) == 10:                                 # fused lateral + fpn (csrc/lat_fpn.hip): W_WBYTES is the 3x3 bank's; + the lateral's weights and, when stored, the lateral itself
+        b += 64 * cp_src * 2 + (tb(int(op[22]) - 1) * n if int(op[22]) > 0 else 0)
     elif int(op[0]) == 9:                                  # fused stem block (csrc/stem_block.hip): W_WBYTES is the first conv's; + the second conv's 64 x 9 x 64 bank and the compact even-pixel output
         b += 64 * 9 * 64 * 2 + (tb(int(op[24]) - 1) * n if int(op[24]) > 0 else 0)
     b += tb(int(op[W_SRC])) * n if int(op[W_SRC]) >= 0 else cn.in_hw[0] * cn.in_hw[1] * 3 * n
@@ -124,7 +126,7 @@ def op_bytes(cn, oi, n):
 
 def mfma_roofline(pipe, frames_dev, batch, F):
     """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs and bytes."""
-    from scrfd_arcface_facerecognition_amd.lower import OP_BBLOCK, OP_CONV, OP_DWPW, OP_MBBLOCK, OP_STEM, OP_STEMBLOCK, OP_STEMFUSED
+    from scrfd_arcface_facerecognition_amd.lower import OP_BBLOCK, OP_CONV, OP_DWPW, OP_LATFPN, OP_MBBLOCK, OP_STEM, OP_STEMBLOCK, OP_STEMFUSED
     tot_ms, tot_flop, tot_bytes, launches, per_net = 0.0, 0.0, 0.0, 0, {}
     for name, cn, imgs, n in (("scrfd_10g", pipe.det, frames_dev, batch), ("arcface_r50", pipe.rec, pipe.crops, batch * F)):
         best = None
@@ -140,7 +142,7 @@ def mfma_roofline(pipe, frames_dev, batch, F):
                     if int(cn.low.ops[oi, 0]) == OP_CONV and int(cn.low.ops[oi, 23]) == 0 and int(cn.low.ops[oi, 29]) > 0
                     and picks.get((int(cn.low.ops[oi, 29]) - 1, n)) == 12}
         for oi, names in enumerate(cn.low.op_nodes):
-            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK, OP_STEMBLOCK):
+            if int(cn.low.ops[oi, 0]) not in (OP_CONV, OP_STEM, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK, OP_STEMBLOCK, OP_LATFPN):
                 continue
             macs = sum(node_macs(cn.net, by_name[nm]) for nm in names)
             fl += 2.0 * macs * n

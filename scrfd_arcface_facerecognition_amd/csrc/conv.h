@@ -130,6 +130,11 @@ bool stem_block_applicable(int H, int W);
 int stem_block_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const float *w0, const float *b0, const float *s0, int act0, const void *w1,
                       const float *b1, int ncls1, const float *s1, int act1, void *out, void *xe);
 
+// lat_fpn.hip: a PAFPN level's 1x1 lateral (+ upsampled coarser lateral) and the 3x3 conv on it in one launch; the lateral leaves the CU only when asked for
+bool lat_fpn_applicable(int Cin_p, int H, int W, int rH, int rW, bool has_res);
+int lat_fpn_launch(fid_ctx *ctx, const void *in, int B, int H, int W, int Cin_p, const void *w0, const float *b0, const void *res, int rH, int rW, const void *w1,
+                   const float *b1, void *out, void *lat);
+
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,
                       const float *b1, const void *w2, const float *b2, void *out, int C2p);

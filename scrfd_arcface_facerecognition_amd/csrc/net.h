@@ -4,7 +4,7 @@
 
 namespace fid {
 
-enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6, OP_DWPW = 7, OP_MBBLOCK = 8, OP_STEMBLOCK = 9 };
+enum : int { OP_STEM = 1, OP_CONV = 2, OP_MAXPOOL = 3, OP_DWCONV = 4, OP_STEMFUSED = 5, OP_BBLOCK = 6, OP_DWPW = 7, OP_MBBLOCK = 8, OP_STEMBLOCK = 9, OP_LATFPN = 10 };
 
 // int32 word indices inside one op record (FID_OP_WORDS = 32 words)
 enum : int {
@@ -47,6 +47,11 @@ enum : int {
     // compact second output (the first conv's result at the even pixels, for the block's stride-2 shortcut; 0: none).  W_ACT = the second conv's
     // activation, W_DST its output, W_F_MACS_* = the MACs of both
     W_S_W1 = 20, W_S_B1 = 21, W_S_S1 = 22, W_S_ACT0 = 23, W_S_DST2 = 24,
+    // OP_LATFPN (lat_fpn.hip; lower.py): a PAFPN level's 1x1 lateral conv (+ the nearest-2x upsampled coarser lateral: W_RES, or -1) and the 3x3 conv
+    // that consumes it, in one launch.  The record is the 3x3 conv's (W_DST, bias W_BOFF; W_WOFF / W_WBYTES = ITS repack-kind-2 image); the lateral's plain
+    // fp16 [64][Cin_p] weights, its bias, and the tensor id + 1 of the lateral itself when a finer level adds it (0: it never leaves the CU);
+    // W_F_MACS_* = the MACs of both
+    W_L_W0 = 20, W_L_B0 = 21, W_L_LAT = 22,
     // OP_CONV fused with the block's shortcut (lower.py; conv_s2.hip DUAL): second output's tensor id + 1 (0: plain conv), its activation,
     // padded couts of the first output; W_F_MACS_LO then holds the shortcut's MACs per image
     W_X_DST2 = 20, W_X_ACT2 = 21, W_X_COUT1P = 22,

@@ -756,6 +756,26 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                                       op[W_S_S1] >= 0 ? (const float *)(blob + op[W_S_S1]) : nullptr, op[W_ACT], dst.ptr, xe));
             break;
         }
+        case OP_LATFPN: {
+            const TensorView src = view(net, op[W_SRC], first);
+            const void *res = nullptr;
+            int rH = 0, rW = 0;
+            if (op[W_RES] >= 0) {
+                const TensorView r = view(net, op[W_RES], first);
+                FID_REQUIRE(r.Cp == 64 && r.dtype == 0, "op %d: coarser lateral", oi);
+                res = r.ptr; rH = r.H; rW = r.W;
+            }
+            FID_REQUIRE(src.dtype == 0 && dst.dtype == 0 && dst.Cp == 64 && src.H == dst.H && src.W == dst.W && lat_fpn_applicable(src.Cp, src.H, src.W, rH, rW, res != nullptr),
+                        "op %d: bad fused lateral + fpn record", oi);
+            void *lat = nullptr;
+            if (op[W_L_LAT] > 0) {
+                const TensorView l = view(net, op[W_L_LAT] - 1, first);
+                FID_REQUIRE(l.Cp == 64 && l.dtype == 0 && l.H == dst.H && l.W == dst.W, "op %d: lateral output of the fused lateral + fpn op", oi);
+                lat = l.ptr;
+            }
+            FID_TRY(lat_fpn_launch(ctx, src.ptr, batch, src.H, src.W, src.Cp, blob + op[W_L_W0], (const float *)(blob + op[W_L_B0]), res, rH, rW, blob + op[W_WOFF], bias, dst.ptr, lat));
+            break;
+        }
         case OP_BBLOCK: {
             const TensorView src = view(net, op[W_SRC], first);
             FID_REQUIRE((src.Cp == 64 || src.Cp == 32) && dst.Cp == src.Cp && src.H == dst.H && src.W == dst.W && src.dtype == 0 && dst.dtype == 0, "op %d: bad fused block record", oi);
@@ -1020,6 +1040,12 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
                      (op[W_ACT] == ACT_RELU || (op[W_ACT] == ACT_PRELU && op[W_S_S1] >= 0)) && op[W_S_DST2] >= 0 && op[W_S_DST2] <= n_tensors &&
                      (op[W_S_DST2] == 0 || net->tensors[(size_t)(op[W_S_DST2] - 1) * FID_TENSOR_WORDS + T_CP] == 64);
                 break;
+            case OP_LATFPN:
+                ok = cp_dst == 64 && (cp_src == 64 || cp_src == 96) && op[W_WOFF] >= 0 && (size_t)op[W_WBYTES] >= (size_t)2 * 73728 && in_blob(op[W_BOFF], 64 * 4) &&
+                     in_blob(op[W_L_W0], (size_t)64 * cp_src * 2) && in_blob(op[W_L_B0], 64 * 4) && op[W_L_LAT] >= 0 && op[W_L_LAT] <= n_tensors &&
+                     (op[W_L_LAT] == 0 || net->tensors[(size_t)(op[W_L_LAT] - 1) * FID_TENSOR_WORDS + T_CP] == 64) &&
+                     (op[W_RES] < 0 || net->tensors[(size_t)op[W_RES] * FID_TENSOR_WORDS + T_CP] == 64);
+                break;
             case OP_STEMFUSED:
                 ok = in_blob(op[W_F_W0], 32 * 32 * 2) && in_blob(op[W_F_B0], 32 * 4) && in_blob(op[W_F_W1], (size_t)32 * 9 * 32 * 2) && in_blob(op[W_F_B1], 32 * 4) &&
                      in_blob(op[W_F_W2], (size_t)cp_dst * 9 * 32 * 2) && in_blob(op[W_F_B2], (size_t)cp_dst * 4);
@@ -1052,7 +1078,7 @@ int fid_net_create(fid_ctx *ctx, const int32_t *ops, int n_ops, const int32_t *t
             return FID_E_INVALID;
         }
         const int32_t *dt = &net->tensors[(size_t)op[W_DST] * FID_TENSOR_WORDS];
-        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK || op[W_TYPE] == OP_DWPW || op[W_TYPE] == OP_MBBLOCK || op[W_TYPE] == OP_STEMBLOCK)
+        if (op[W_TYPE] == OP_STEMFUSED || op[W_TYPE] == OP_BBLOCK || op[W_TYPE] == OP_DWPW || op[W_TYPE] == OP_MBBLOCK || op[W_TYPE] == OP_STEMBLOCK || op[W_TYPE] == OP_LATFPN)
             net->macs_per_image += (double)(((unsigned long long)(unsigned)op[W_F_MACS_HI] << 32) | (unsigned)op[W_F_MACS_LO]);
         if (op[W_TYPE] == OP_CONV && op[W_X_DST2] > 0) net->macs_per_image += (double)(unsigned)op[W_F_MACS_LO];   // the fused shortcut's share
         if (op[W_TYPE] == OP_CONV || op[W_TYPE] == OP_STEM || op[W_TYPE] == OP_DWCONV)

@@ -15,6 +15,8 @@ models/scrfd.py:59-62, models/arcface.py:18-21), written down:
   * the three SCRFD output convs of a level become one conv with 2+8+20 output channels, sigmoid on
     the first two, bbox scale folded in, fp32 output;
   * blobFromImage's (x-127.5)*scale and BGR->RGB swap are folded into the first conv's weights;
+  * a PAFPN level's 1x1 lateral conv (+ the upsampled coarser lateral) and the 3x3 conv on it become ONE op (csrc/lat_fpn.hip): the lateral is
+    stored only when a finer level adds it (FID_NO_LATFPN_FUSE=1 keeps the two convs apart);
   * IResNet's first conv (3 -> 64, stride 1) and the 3x3 conv on 64 channels that consumes it become ONE op (csrc/stem_block.hip): the first
     conv's map only exists in LDS; the block's 1x1 / stride-2 shortcut reads a compact copy of it at the even pixels (FID_NO_STEMBLOCK_FUSE=1
     keeps the two convs apart);
@@ -33,7 +35,7 @@ import numpy as np
 from .archs import BN_EPS, Net, infer_shapes
 
 OP_WORDS, TENSOR_WORDS = 32, 8
-OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK, OP_STEMBLOCK = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_STEM, OP_CONV, OP_MAXPOOL, OP_DWCONV, OP_STEMFUSED, OP_BBLOCK, OP_DWPW, OP_MBBLOCK, OP_STEMBLOCK, OP_LATFPN = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 ACT = {"none": 0, "relu": 1, "prelu": 2}
 CF_RES_UP2, CF_BORDER, CF_OUT_F32 = 1, 2, 4
 CPAD = 32
@@ -166,6 +168,40 @@ def _mbf_block(net, i, tensors, tid, shp):
     if rup(81 * (cin_p * 2 + 16)) + rup(81 * (gp * 2 + 16)) + ((to * to + 15) // 16 * 16) * (gp * 2 + 16) > 160 * 1024:
         return None
     return d, m
+
+
+def _latfpn(net, i, tensors, tid):
+    """node i = a 1x1 lateral conv (bias / BN, no activation, optionally + the nearest-2x upsampled coarser lateral) on 64 / 96 stored channels whose
+    consumers are ONE 3x3 / stride-1 conv without activation or residual (64 stored couts each) and otherwise only finer laterals that add it
+    (res_up2): (index of the 3x3 conv, that node, lateral stored?) or None (csrc/lat_fpn.hip)"""
+    import os
+    n = net.nodes[i]
+    if os.environ.get("FID_NO_LATFPN_FUSE") or not (n.kind == "conv" and n.k == 1 and n.pad == 0 and n.stride == 1 and n.groups == 1 and n.act == "none"
+                                                    and not n.pre_bn and not n.pre_avgpool and n.src != "input" and n.name not in net.outputs
+                                                    and (n.res is None or n.res_up2) and _rup(n.cout, CPAD) == 64):
+        return None
+    src_t = tensors[tid[n.src]]
+    if src_t[4] != 0 or src_t[1] not in (64, 96) or src_t[2] < 3 or src_t[3] < 3:
+        return None
+    if n.res is not None:
+        r_t = tensors[tid[n.res]]
+        if r_t[4] != 0 or r_t[1] != 64 or r_t[2] < (src_t[2] + 1) // 2 or r_t[3] < (src_t[3] + 1) // 2:
+            return None
+    convs, adders = [], 0
+    for j, x in enumerate(net.nodes):
+        if getattr(x, "src", None) == n.name:
+            convs.append((j, x))
+        if getattr(x, "res", None) == n.name:
+            if not (x.kind == "conv" and x.res_up2 and x.src != n.name):
+                return None
+            adders += 1
+    if len(convs) != 1:
+        return None
+    j, m = convs[0]
+    if not (j > i and m.kind == "conv" and m.k == 3 and m.stride == 1 and m.pad == 1 and m.groups == 1 and m.act == "none" and m.res is None and not m.pre_bn
+            and not m.pre_avgpool and m.cin == n.cout and _rup(m.cout, CPAD) == 64):
+        return None
+    return j, m, adders > 0
 
 
 def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
@@ -535,6 +571,31 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             out.fused_groups[m.name] = [n.name, d.name, m.name]
             skip.add(ni_ + 1)
             skip.add(ni_ + 2)
+        elif n.kind == "conv" and n.groups == 1 and _latfpn(net, ni_, tensors, tid) is not None:
+            # A PAFPN level: lateral 1x1 (+ upsampled coarser lateral) and the 3x3 conv on it as ONE launch (csrc/lat_fpn.hip); the lateral is a
+            # tensor of its own only when a finer level adds it.  The record is the 3x3 conv's; words 20-22: the lateral's weights / bias / tensor.
+            mj, m, keep_lat = _latfpn(net, ni_, tensors, tid)
+            src_t = tensors[tid[n.src]]
+            W0, b0 = folded(n)
+            w0off = blob.add(pack_weights(W0, src_t[1], 64).reshape(64, src_t[1]))[0]
+            b0off = blob.add(padded(b0, 64))[0]
+            W1, b1 = folded(m)
+            w1off, w1bytes = blob.add(repack_kind2(pack_weights(W1, 64, 64)))
+            b1off = blob.add(padded(b1, 64)[None, :])[0]
+            _, ho, wo = shp[m.name]
+            lat_t = new_tensor(n.name, n.cout, ho, wo) + 1 if keep_lat else 0
+            dst = new_tensor(m.name, m.cout, ho, wo)
+            emit(m.name, type=OP_LATFPN, src=tid[n.src], dst=dst, res=tid[n.res] if n.res else -1, kh=3, kw=3, stride=1, pad=1, cin=m.cin, cout=m.cout,
+                 act=0, flags=0, woff=w1off, wbytes=w1bytes, boff=b1off, soff=-1, wrows=64)
+            r = ops[-1]
+            r[20], r[21], r[22] = w0off, b0off, lat_t
+            macs = ho * wo * (n.cout * n.cin + m.cout * m.cin * 9)
+            r[26], r[27] = macs & 0xFFFFFFFF, macs >> 32
+            if r[26] >= 2 ** 31:
+                r[26] -= 2 ** 32
+            op_nodes[-1] = [n.name, m.name]
+            out.fused_groups[m.name] = [n.name, m.name]
+            skip.add(mj)
         elif n.kind == "conv" and n.groups == 1:
             cin, cout = n.cin, n.cout
             _, ho, wo = shp[n.name]
@@ -695,6 +756,8 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
         dsts = [rec[2]] + ([rec[20] - 1] if rec[0] == OP_CONV and rec[20] > 0 else [])    # (a fused shortcut + conv op writes two tensors)
         if rec[0] == OP_STEMBLOCK and rec[24] > 0:
             dsts.append(rec[24] - 1)                                                      # (... and so does the fused stem block)
+        if rec[0] == OP_LATFPN and rec[22] > 0:
+            dsts.append(rec[22] - 1)                                                      # (... and the fused lateral + fpn op when a finer level adds its lateral)
         for d in dsts:
             need = nbytes(d)
             if d in keep or not free:

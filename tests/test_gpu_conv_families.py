@@ -421,3 +421,48 @@ def test_fused_stem_block(ctx, monkeypatch, fuse, hw, pre_bn, act, block, batch)
         r = np.transpose(ref["stem"], (0, 2, 3, 1))[:, ::2, ::2]
         assert got["stem.even"].shape == r.shape
         assert np.abs(got["stem.even"] - r).max() / np.abs(r).max() < 3e-3
+
+
+# A PAFPN level as one launch (csrc/lat_fpn.hip, round 4): lateral 1x1 (+ nearest-2x upsampled coarser lateral) and the 3x3 conv on it; the lateral
+# is stored only when a finer level adds it.  Fused and unfused (FID_NO_LATFPN_FUSE=1) lowering against the oracle: two levels (the coarse one's
+# lateral is stored AND consumed on chip, the fine one's never leaves the CU), 96- and 64-channel sources, tile-multiple and ragged maps
+# (every level exactly twice the next one: the oracle's nearest-2x upsample needs that, as the reference's PAFPN does)
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("hw,cch,batch", [((80, 80), 88, 2), ((40, 56), 88, 3), ((16, 16), 88, 1), ((52, 36), 64, 2), ((24, 72), 56, 5)])
+def test_fused_lateral_fpn(ctx, monkeypatch, fuse, hw, cch, batch):
+    from scrfd_arcface_facerecognition_amd import lower
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    if not fuse:
+        monkeypatch.setenv("FID_NO_LATFPN_FUSE", "1")
+    kw = dict(bias=True, post_bn=False)
+    net = Net("t", hw, 127.5, 1.0 / 128.0)
+    net.add(Conv("s", "input", 3, 32, act="relu"))
+    net.add(Conv("c3", "s", 32, cch, act="relu"))
+    net.add(Conv("c4", "c3", cch, cch, stride=2, act="relu"))
+    net.add(Conv("c5", "c4", cch, cch, stride=2, act="relu"))
+    net.add(Conv("lat2", "c5", cch, 56, k=1, pad=0, **kw))
+    net.add(Conv("lat1", "c4", cch, 56, k=1, pad=0, res="lat2", res_up2=True, **kw))
+    net.add(Conv("lat0", "c3", cch, 56, k=1, pad=0, res="lat1", res_up2=True, **kw))
+    net.add(Conv("fpn0", "lat0", 56, 56, **kw))
+    net.add(Conv("fpn1", "lat1", 56, 56, **kw))
+    net.add(Conv("fpn2", "lat2", 56, 56, **kw))
+    net.outputs = ["fpn0", "fpn1", "fpn2"]
+    P = archs.synth_params(net, seed=81)
+    low = lower.lower(net, P)
+    n_fused = sum(int(r[0]) == lower.OP_LATFPN for r in low.ops)
+    assert n_fused == (3 if fuse else 0), low.op_names
+    if fuse:
+        assert "lat0" not in low.tensor_id and "lat1" in low.tensor_id and "lat2" in low.tensor_id     # only the laterals a finer level adds are stored
+    images = np.random.default_rng(16).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    for _ in range(2):
+        cn.run(images)
+    got = {o: cn.read(o, batch) for o in net.outputs}
+    if fuse:
+        got["lat1"] = cn.read("lat1", batch)
+    cn.close()
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean), keep=["lat1"])
+    for o, g in got.items():
+        r = np.transpose(ref[o], (0, 2, 3, 1))
+        assert g.shape == r.shape
+        assert np.abs(g - r).max() / np.abs(r).max() < 6e-3, (o, hw)

@@ -16,7 +16,7 @@ import os
 import sys
 
 CONV = ("conv_mfma_kernel", "conv_mfma_dma_kernel", "conv3x3_direct", "conv3x3_chunked", "conv3x3_pp", "conv3x3_pc", "conv_mfma_pc_kernel", "conv3x3_wr", "conv3x3_s2", "conv_gw",
-        "scrfd_stem_fused", "stem_conv_mfma", "conv_bb", "conv3x3_ks", "scrfd_stem_rows", "dwpw_kernel", "mbf_block", "ir_stem_block")
+        "scrfd_stem_fused", "stem_conv_mfma", "conv_bb", "conv3x3_ks", "scrfd_stem_rows", "dwpw_kernel", "mbf_block", "ir_stem_block", "lat_fpn")
 
 
 def total(run_dir, counter):
