@@ -75,12 +75,14 @@ def test_full_size_properties(plan, monkeypatch):
     # without the generation-9/10 kernels) and 1.1e-3 .. 1.6e-3 on the stride-8 / 16 heads: summation-order noise, not a kernel property)
     from oracle import align as oalign, nets as onets, pipeline as opipe
     run(frames)
+    worst = {}
     for fi in (0, 21, 42, 63):
         blob = oalign.blob_from_images([frames[fi]], det_net.in_scale, det_net.in_mean)
         ref = onets.run_net(det_net, det_P, blob)
         for name in det_net.outputs:
             fused = det.read(name, B)[fi:fi + 1]
             sc_, bb_, kp_ = ref[name]
+            worst[name] = max(worst.get(name, 0.0), float(np.abs(fused[..., 0:2].reshape(1, -1, 1) - sc_).max()))
             assert np.abs(fused[..., 0:2].reshape(1, -1, 1) - sc_).max() < 4e-3, (fi, name)
             assert np.abs(fused[..., 2:10].reshape(1, -1, 4) - bb_).max() < 3e-2, (fi, name)
             assert np.abs(fused[..., 10:30].reshape(1, -1, 10) - kp_).max() < 3e-2, (fi, name)
@@ -89,6 +91,7 @@ def test_full_size_properties(plan, monkeypatch):
         e = emb[fi]
         assert 1 - float(oe @ e / np.linalg.norm(oe) / np.linalg.norm(e)) < 1e-3, fi
         assert np.abs(oe / np.linalg.norm(oe) - e / np.linalg.norm(e)).max() < 1e-3, fi
+    print(f"\nworst |score - oracle| per head on 4 frames (plan={plan}): " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
 
     # NMS idempotence on one frame's full detection list
     pipe2 = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=F)
@@ -106,7 +109,7 @@ def test_full_size_properties(plan, monkeypatch):
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     fused = [det.read(name, B) for name in det_net.outputs]
     cnt_all, det_all, kps_all = pipe2.post.counts.download()[:B], pipe2.post.det.download(), pipe2.post.kps.download()
-    per_frame = []
+    per_frame, worst64 = [], [0.0, 0.0, 0.0]
     for fi in range(B):
         dev_outs = oagree.fused_to_session_outputs(fused, fi)
         od, ok = opp.detect_from_heads(dev_outs, (640, 640), (640, 640), 0.5, 0.4, 0)
@@ -116,8 +119,10 @@ def test_full_size_properties(plan, monkeypatch):
         blob = oalign.blob_from_images([frames[fi]], det_net.in_scale, det_net.in_mean)
         ref_outs = onets.scrfd_session_outputs(det_net, det_P, blob)
         per_frame.append(oagree.survivor_agreement(ref_outs, dev_outs, (640, 640), 0.5, 0.4, margin=5e-3))
+        for li in range(3):                                           # session outputs 0..2 = the three strides' scores
+            worst64[li] = max(worst64[li], float(np.abs(np.asarray(dev_outs[li], np.float32) - ref_outs[li]).max()))
     agree = oagree.summarize(per_frame)
-    print(f"\ndet_survivor_agreement (plan={plan}): {agree}")
+    print(f"\ndet_survivor_agreement (plan={plan}): {agree}; worst |score - oracle| over all {B} frames per stride: " + " ".join(f"{v:.2e}" for v in worst64))
     assert agree["unexplained"] == 0, [(fi, d["detail"]) for fi, d in enumerate(per_frame) if d["unexplained"]]
     assert agree["matched"] >= 0.9 * agree["survivors_a"], agree
     n0 = int(pipe2.post.counts.download()[0])
