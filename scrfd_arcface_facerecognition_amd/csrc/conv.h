@@ -134,6 +134,9 @@ int stem_block_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, con
 bool lat_fpn_applicable(int Cin_p, int H, int W, int rH, int rW, bool has_res);
 int lat_fpn_launch(fid_ctx *ctx, const void *in, int B, int H, int W, int Cin_p, const void *w0, const float *b0, const void *res, int rH, int rW, const void *w1,
                    const float *b1, void *out, void *lat);
+// match_gemm.hip: the gallery scan on 256 x 256 tiles (query batches > 128 rows against galleries of >= one tile per CU)
+bool match_scan256_applicable(int n, int Gp, int dim, int num_cus);
+int match_scan256_launch(fid_ctx *ctx, const void *q, const void *g, int n, int Gp, int dim, int col0, unsigned long long *amax);
 
 // stem_fused.hip: u8 frame -> conv/s2 -> conv -> conv -> maxpool/s2 in one kernel
 int stem_fused_launch(fid_ctx *ctx, const uint8_t *img, int B, int H, int W, const void *w0, const float *b0, const void *w1,

@@ -131,6 +131,8 @@ __global__ void __launch_bounds__(256) match_finalize(const unsigned long long *
 }
 
 int gemm_vs_gallery(fid_ctx *ctx, fid_gallery *g, const void *q, int n, int flags, void *out, unsigned long long *amax, int col0 = 0) {
+    if (flags == CF_ARGMAX && match_scan256_applicable(n, g->Gp, g->dim, ctx->num_cus))
+        return match_scan256_launch(ctx, q, g->unit_f16, n, g->Gp, g->dim, col0, amax);
     ConvArgs a{};
     a.in = q;
     a.w = g->unit_f16;

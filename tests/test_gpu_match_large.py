@@ -53,7 +53,8 @@ def make_queries(g, n, dup_pairs, seed):
     q = rng.standard_normal((n, DIM), dtype=np.float32)
     planted = {}
     targets = [0, 1, 126, 127, 128, 129, 255, 256, 128 * 8 - 1, 128 * 8, 128 * 64 - 1, 128 * 64, G - 1, G - 2, G - 33,
-               (G // 128) * 128, (G // 128) * 128 - 1, 4241, 4243]
+               (G // 128) * 128, (G // 128) * 128 - 1, 4241, 4243,
+               256 * 31 - 1, 256 * 31, 256 * 62 - 1, 256 * 62, (G // 256) * 256 - 1, (G // 256) * 256]   # tile-range borders of the 256 x 256 scan
     targets += [hi for _, hi in dup_pairs]            # queries aimed at the HIGHER copy: the lower index must be returned
     k = 0
     for i in range(0, n, 2):
@@ -140,6 +141,33 @@ def test_match_large_gallery_vs_oracle(ctx, big, n, chunk):
     if n == 10000 and G == 100_000:
         pytest.skip("cfg 4 pairs 10 k crops with the 1 M gallery; 100 k x 10 k adds nothing over 512")
     check_match(ctx, big, n, chunk)
+
+
+@pytest.mark.parametrize("n", [129, 300, 500, 512, 777])
+def test_scan256_equals_the_generic_gemm(ctx, big, n, monkeypatch):
+    """csrc/match_gemm.hip (256 x 256 tiles, running arg-max in registers) against the generic GEMM + atomicMax epilogue it replaces for
+    batches of more than 128 queries: same indices everywhere (thr = 0: every query reports its arg-max), scores to 1e-5 -- ragged query
+    tiles (129, 300, 500, 777), exact duplicates across tiles and workgroup ranges, zero rows, the last real row before the padding."""
+    G, g, g_unit, dup_pairs, zero_row, gal = big
+    q, planted = make_queries(g, n, dup_pairs, seed=n)
+    qd = gpu_normalize(ctx, q)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("FID_NO_MATCH256", "1")
+        else:
+            monkeypatch.delenv("FID_NO_MATCH256", raising=False)
+        idx, sc = ctx.empty((n,), np.int32), ctx.empty((n,), np.float32)
+        gal.match_device(qd, n, 0.0, idx, sc)
+        out.append((idx.download(), sc.download()))
+    monkeypatch.delenv("FID_NO_MATCH256", raising=False)
+    (i_new, s_new), (i_old, s_old) = out
+    low_of = {hi: lo for lo, hi in dup_pairs}
+    for i, t in planted.items():
+        assert i_new[i] == low_of.get(t, t), (i, i_new[i], t)
+    assert np.abs(s_new - s_old).max() < 1e-5
+    differ = i_new != i_old                              # (only where two rows' fp32 sums are equal to the last bit -- none expected)
+    assert not differ.any(), np.flatnonzero(differ)[:10]
 
 
 def test_low_threshold_argmax_near_ties(ctx, big):
