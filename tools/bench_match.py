@@ -13,7 +13,10 @@ from scrfd_arcface_facerecognition_amd.engine import Gallery  # noqa: E402
 
 ctx = Context(0)
 rng = np.random.default_rng(0)
-for G, n in ((1000, 64), (100_000, 512), (1_000_000, 512), (1_000_000, 10_000)):
+CASES = ((1000, 64), (100_000, 512), (1_000_000, 512), (1_000_000, 10_000))
+if len(sys.argv) > 1:                                   # bench_match.py G n: one case (ablation runs)
+    CASES = ((int(sys.argv[1]), int(sys.argv[2])),)
+for G, n in CASES:
     gal_h = rng.standard_normal((G, 512), dtype=np.float32)
     gal = Gallery(ctx, gal_h)
     emb = rng.standard_normal((n, 512), dtype=np.float32)
