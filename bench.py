@@ -323,7 +323,9 @@ def main():
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
     from scrfd_arcface_facerecognition_amd.pipeline import (Communicator, FacePipeline, build_targets_from_images,
                                                             calibrate_detector_bias, run_step_distributed, shard_range)
-    stream = torch.cuda.Stream()
+    # experiment hook (docs/HOOKS.md): FID_BENCH_PRIO="p0,p1" = HIP stream priority per lane (torch: -1 high, 0 default)
+    prios = [int(x) for x in os.environ.get("FID_BENCH_PRIO", "").split(",") if x.strip()]
+    stream = torch.cuda.Stream(priority=prios[0]) if prios else torch.cuda.Stream()
     ctx = Context(local_rank, stream.cuda_stream)
     B, F = args.batch, args.faces_per_frame
     G = args.gallery or (1000 if world == 1 else 100_000)
@@ -370,7 +372,7 @@ def main():
         if li == 0:
             ln.stream, ln.ctx, ln.det, ln.rec, ln.gallery = stream, ctx, det, rec, gallery
         else:
-            ln.stream = torch.cuda.Stream()
+            ln.stream = torch.cuda.Stream(priority=prios[li]) if li < len(prios) else torch.cuda.Stream()
             ln.ctx = Context(local_rank, ln.stream.cuda_stream)
             ln.det = CompiledNet(ln.ctx, det_net, det_P, max_batch=B)
             ln.rec = CompiledNet(ln.ctx, rec_net, rec_P, max_batch=B * F)
