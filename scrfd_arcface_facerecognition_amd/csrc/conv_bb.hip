@@ -65,7 +65,8 @@ struct BBArgs {
     FastDiv d_tpi, d_tx;
     unsigned io_bytes;        // bytes of the input (= output) tensor
     int rev;                  // ConvArgs::rev
-    int ablate;               // FID_BB_ABLATE timing experiments (wrong results): 1 no conv1, 2 no conv2, 4 no stores, 8 no patch fetch
+    int ablate;               // FID_BB_ABLATE timing experiments (wrong results): 1 no conv1, 2 no conv2, 4 no stores, 8 no patch fetch; conv_bb2 also 16 no conv1 epilogue, 32 no conv2 epilogue, 64 two barriers fewer
+    int stagger;              // FID_BB_STAGGER (conv_bb2): the second half of the grid starts this many x 64 sleep ticks late
 };
 
 // IR = false: SCRFD's block (plain bias + ReLU after conv1; the bias lives in registers).  IR = true: any conv1 epilogue -- bias rows by border
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
 
         // ================= A: conv1 on the 16x16 region (rows 8 rg .. 8 rg + 7 here) =================
 #pragma unroll
-        for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 8; r++) acc[r] = IR ? f32x4{0.f, 0.f, 0.f, 0.f} : bias1;      // (plain form: the bias is the accumulators' start value, no add in the epilogue)
         if (!(a.ablate & 1)) {
             const int xo = OFF_X + buf * X_ITEM + rg * (8 * PW * 64);
             conv_phase(xo, integral_constant<int, 8>{}, integral_constant<int, PW>{}, integral_constant<int, P_BYTES>{}, w1, fetch_hook);
@@ -251,6 +252,8 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
             const int fr = lo & 15, q4 = lo >> 4;
             const int gx = tx * TO - 1 + fr, gy0 = ty * TO - 1 + rg * 8;
             const bool xin = (unsigned)gx < (unsigned)a.W;
+            // (a tile whose 16x16 region lies inside the image has no padding pixel to clear: wave-uniform, most tiles)
+            const bool edge = ty == 0 || tx == 0 || ty * TO + 15 > a.H || tx * TO + 15 > a.W;
             char *mp = smem + OFF_MID + (cw >> 1) * MID_CH + (rg * 8 * MW + fr) * 64 + ((((cw & 1) * 2 + (q4 >> 1)) ^ swz64(fr)) << 4) + (q4 & 1) * 8;
             const int xc = a.ncls1 == 9 ? (gx == 0 ? 0 : (gx == a.W - 1 ? 2 : 1)) : 0;
             const float *tb = (const float *)(smem + OFF_TAB) + xc * 64 + cw * 16 + q4 * 4;
@@ -263,9 +266,9 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
                     v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + slope1 * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
                     h = __builtin_convertvector(v, half4);
                 } else {
-                    h = __builtin_elementwise_max(__builtin_convertvector(acc[i] + bias1, half4), half4{0, 0, 0, 0});
+                    h = __builtin_elementwise_max(__builtin_convertvector(acc[i], half4), half4{0, 0, 0, 0});
                 }
-                if (!(xin && (unsigned)(gy0 + i) < (unsigned)a.H)) h = half4{0, 0, 0, 0};
+                if (edge && !(xin && (unsigned)(gy0 + i) < (unsigned)a.H)) h = half4{0, 0, 0, 0};
                 *(half4 *)(mp + i * (MW * 64)) = h;
             }
         }
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
 
         // ================= B: conv2 on the 14x14 tile (rows 7 rg .. 7 rg + 6 here) =================
 #pragma unroll
-        for (int r = 0; r < 8; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 8; r++) acc[r] = bias2;
         if (!(a.ablate & 2)) {
             const int mo = OFF_MID + rg * (7 * MW * 64);
             conv_phase(mo, integral_constant<int, 7>{}, integral_constant<int, MW>{}, integral_constant<int, MID_CH>{}, w2, no_hook);
@@ -296,7 +299,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
 #pragma unroll
             for (int i = 0; i < 7; i++) {
                 const int r = rg * 7 + i;
-                f32x4 v = acc[i] + bias2 + __builtin_convertvector(rs[i], f32x4);
+                f32x4 v = acc[i] + __builtin_convertvector(rs[i], f32x4);
                 half4 h = __builtin_convertvector(v, half4);
                 if (a.act2 == ACT_RELU) h = __builtin_elementwise_max(h, half4{0, 0, 0, 0});
                 *(half4 *)(sp + r * (16 * ROWB)) = h;
@@ -308,6 +311,255 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
     raw_barrier();                                              // the last tile is staged
     write_out(pn, pty, ptx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the surplus pieces target this workgroup's LDS: drain before exit
+}
+
+
+// ======================================================================================================================================
+// The 64-channel block as TWO independent workgroups of FOUR waves per CU (round 4, second session; opt-in with `FID_BB_V=2`: measured equal
+// alone and 1 % slower in the two-lane bench step, docs/FINDINGS.md).
+// The eight-wave kernel above is one lock-step group per CU: both waves of a SIMD reach the conv1 / conv2 epilogues, the barriers and the
+// patch wait together, and the matrix pipe idles through all of them (60 % MFMA-busy, conv phases 211 of 272 us).  conv_bb32 showed what two
+// workgroups per CU buy (their epilogues and waits interleave); here they have to fit 80 KB of LDS each:
+//   wave  = cout fragment cw = 0..3 for ALL rows: the two row groups of the eight-wave kernel (conv1 rows 8 rg .. 8 rg + 7, conv2 rows
+//           7 rg .. 7 rg + 6) run one after the other on the same 8 accumulator rows -- same registers per wave (both filter banks: 144)
+//   LDS   = ONE x-patch buffer (43 KB) + the intermediate tile (32 KB) + bias table: 79.6 KB.  No second patch buffer and no staging area:
+//           the finished tile is written IN PLACE over the x patch (a lane's residual values sit exactly where its results go: patch pixel
+//           (row + 2, column + 2), its couts' 8 bytes), the 16-byte row stores read it from there, and only then is the next item's patch
+//           requested -- that wait (~2-3 us per item) is what the other workgroup's matrix phases cover.
+//   order = [wait my pieces | barrier] conv1 rg 0, rg 1 -> mid [barrier] conv2 rg 0, rg 1 -> x in place [barrier] row stores [barrier] request
+//           the next patch.  Every wait is a full drain: no hand-counted operation.
+// ======================================================================================================================================
+constexpr int NW2 = 4;
+constexpr int MAX_P2 = (N_PIECES + NW2 - 1) / NW2;               // 11 pieces per wave (two surplus ones go to the spare KB)
+constexpr int ST_I2 = (TO * 16 * CPX + NW2 * 64 - 1) / (NW2 * 64);   // 7 stores per thread and item: two tile rows per round
+constexpr int OFF2_X = 0, OFF2_SPARE = X_ITEM, OFF2_MID = OFF2_SPARE + 1024, OFF2_TAB = OFF2_MID + MID_BYTES + 512, LDS2_BYTES = OFF2_TAB + TAB_BYTES;
+static_assert(LDS2_BYTES <= 80 * 1024 && ST_I2 * 2 == TO, "two workgroups per CU; a store round covers two tile rows");
+
+template <bool IR>
+__global__ void __launch_bounds__(NW2 * 64, 2) conv_bb2(const BBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, cw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int bid = xcd_major_id(blockIdx.x, gridDim.x);
+    const int my_items = bid < a.n_tiles ? (a.n_tiles - 1 - bid) / gridDim.x + 1 : 0;
+    if (my_items == 0) return;
+
+    auto decode_tile = [&](int item, int &n, int &ty, int &tx) {
+        if (a.rev) item = a.n_tiles - 1 - item;
+        n = fastdiv(item, a.d_tpi);
+        const int r = item - n * a.tiles_per_img;
+        ty = fastdiv(r, a.d_tx); tx = r - ty * a.tiles_x;
+    };
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.io_bytes, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, a.io_bytes, 0x00020000);
+
+    int p_pk[MAX_P2];                                           // py | px << 8 | channel offset (halfs) << 16; py = 255: nothing to fetch
+#pragma unroll
+    for (int k = 0; k < MAX_P2; k++) {
+        const int j = cw + NW2 * k;
+        const int ch = j / P_BLKS, blk = j - ch * P_BLKS;
+        const int row = blk * 16 + (lane >> 2);
+        int py = row / PW;
+        const int px = row - py * PW;
+        if (row >= NPIX || j >= N_PIECES) py = 255;
+        p_pk[k] = py | (px << 8) | (((((lane & 3) ^ swz64(row)) * 8) + ch * 32) << 16);
+    }
+    auto issue_patch = [&](int n, int ty, int tx, bool live) {  // my MAX_P2 pieces of the patch of tile (n, ty, tx)
+        const int y0 = ty * TO - 2, x0 = tx * TO - 2;
+#pragma unroll
+        for (int k = 0; k < MAX_P2; k++) {
+            const int j = cw + NW2 * k;
+            int pk = p_pk[k];
+            asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
+            const int py = pk & 255, iy = y0 + py, ix = x0 + ((pk >> 8) & 255);
+            const bool in = live && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 8);
+            const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * 64 + (pk >> 16)) * 2) : OOB;
+            char *d = j < N_PIECES ? smem + OFF2_X + j * 1024 : smem + OFF2_SPARE;     // surplus piece: zeros into the spare KB
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)d, 16, vo, 0, 0, 0);
+        }
+    };
+    if (a.stagger && blockIdx.x >= gridDim.x / 2)               // experiment (FID_BB_STAGGER): the co-resident half of the grid starts late
+        for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(64);
+    {
+        int n, ty, tx;
+        decode_tile(bid, n, ty, tx);
+        issue_patch(n, ty, tx, true);
+    }
+
+    // ---- both filter banks of my 16 couts: kind 2 = [chunk][cout fragment 0..7][dx][dy][lane] x 16 B
+    half8 w1[18], w2[18];                                       // [chunk * 9 + dy * 3 + dx]
+    {
+        const char *p1 = (const char *)a.w1 + cw * 9216 + lane * 16, *p2 = (const char *)a.w2 + cw * 9216 + lane * 16;
+#pragma unroll
+        for (int ck = 0; ck < 2; ck++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    w1[ck * 9 + dy * 3 + dx] = *(const half8 *)(p1 + ck * (8 * 9216) + dx * 3072 + dy * 1024);
+                    w2[ck * 9 + dy * 3 + dx] = *(const half8 *)(p2 + ck * (8 * 9216) + dx * 3072 + dy * 1024);
+                }
+    }
+    const f32x4 bias1 = *(const f32x4 *)(a.b1 + cw * 16 + fq * 4), bias2 = *(const f32x4 *)(a.b2 + cw * 16 + fq * 4);
+    f32x4 slope1 = f32x4{0.f, 0.f, 0.f, 0.f};                   // (ReLU = PReLU with slope 0)
+    if constexpr (IR) {
+        if (a.act1 == ACT_PRELU) slope1 = *(const f32x4 *)(a.s1 + cw * 16 + fq * 4);
+        float *tb = (float *)(smem + OFF2_TAB);
+        for (int i = tid; i < a.ncls1 * 64; i += NW2 * 64) tb[i] = a.b1[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 18; i++) asm volatile("" : "+v"(w1[i]), "+v"(w2[i]));
+
+    int pbase[2][4];
+#pragma unroll
+    for (int par = 0; par < 2; par++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) pbase[par][c] = frow * 64 + ((fq ^ ((((frow + par) >> 1) + c) & 3)) << 4);
+
+    f32x4 acc[8];
+    constexpr int PD = BB_PD;
+    auto conv_phase = [&](int base_off, auto rows_tag, auto pw_tag, auto cs_tag, const half8 *wv) {
+        constexpr int ROWS = decltype(rows_tag)::value, PWV = decltype(pw_tag)::value, CS = decltype(cs_tag)::value, PH = ROWS + 2, NQ = 6 * PH;
+        int pb[2][4];
+#pragma unroll
+        for (int par = 0; par < 2; par++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                pb[par][c] = pbase[par][c] + base_off;
+                asm volatile("" : "+v"(pb[par][c]));
+            }
+        half8 pq[PD + 1];
+        auto load_p = [&](int q) {                              // q = (chunk * 3 + dx) * PH + fragment row
+            const int pass = q / PH, r = q - pass * PH, ck = pass / 3, dx = pass - ck * 3;
+            const int K = r * PWV + dx;
+            pq[q % (PD + 1)] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + (K * 64 + ck * CS)));
+        };
+#pragma unroll
+        for (int q = 0; q < PD; q++) load_p(q);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int pass = q / PH, r = q - pass * PH, ck = pass / 3, dx = pass - ck * 3;
+            if (q + PD < NQ) load_p(q + PD);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+                const int mi = r - dy;
+                if (mi < 0 || mi >= ROWS) continue;
+                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[ck * 9 + dy * 3 + dx], pq[q % (PD + 1)], acc[mi], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using std::integral_constant;
+
+    // row stores of the finished tile, read from where it was written in place: 16-byte slot = (pixel q0 = thread / 8 of a two-row round,
+    // couts 8 c .. 8 c + 7 = group c & 3 of chunk c >> 2)
+    auto write_out = [&](int n, int ty, int tx) {
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int q0 = t2 >> 3, c = t2 & 7;
+        const int pr0 = q0 >> 4, pc = q0 & 15;
+        const int oy0 = ty * TO, ox = tx * TO + pc;
+        const bool okc = pc < TO && ox < a.W && !(a.ablate & 4);
+        const char *lsrc = smem + OFF2_X + (c >> 2) * P_BYTES;
+        const unsigned g0 = (unsigned)((((n * a.H + oy0 + pr0) * a.W + ox) * 64 + c * 8) * 2);
+        const unsigned rstride = (unsigned)(a.W * 64 * 2);
+#pragma unroll
+        for (int i = 0; i < ST_I2; i++) {
+            const int row = 2 * i + pr0, lin = (row + 2) * PW + pc + 2;
+            const u32x4 v = *(const u32x4 *)(lsrc + lin * 64 + (((c & 3) ^ swz64(lin)) << 4));
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (okc && oy0 + row < a.H) ? g0 + (unsigned)(2 * i) * rstride : OOB, 0, 0);
+        }
+    };
+
+    int item = bid;
+    for (int it = 0; it < my_items; it++, item += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();                                          // everybody's pieces of this item's patch have landed
+        int n, ty, tx;
+        decode_tile(item, n, ty, tx);
+
+        // ================= A: conv1 on the 16x16 region, rows 8 rg .. 8 rg + 7 per pass =================
+#pragma nounroll
+        for (int rg = 0; rg < 2; rg++) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) acc[r] = IR ? f32x4{0.f, 0.f, 0.f, 0.f} : bias1;
+            if (!(a.ablate & 1))
+                conv_phase(OFF2_X + rg * (8 * PW * 64), integral_constant<int, 8>{}, integral_constant<int, PW>{}, integral_constant<int, P_BYTES>{}, w1);
+            if (a.ablate & 16) continue;
+            // intermediate pixel (row 8 rg + i, column frow) = image pixel (ty*14 - 1 + row, tx*14 - 1 + frow); outside the image it is
+            // conv2's zero padding, NOT conv1 evaluated there
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int fr = lo & 15, q4 = lo >> 4;
+            const int gx = tx * TO - 1 + fr, gy0 = ty * TO - 1 + rg * 8;
+            const bool xin = (unsigned)gx < (unsigned)a.W;
+            const bool edge = ty == 0 || tx == 0 || ty * TO + 15 > a.H || tx * TO + 15 > a.W;
+            char *mp = smem + OFF2_MID + (cw >> 1) * MID_CH + (rg * 8 * MW + fr) * 64 + ((((cw & 1) * 2 + (q4 >> 1)) ^ swz64(fr)) << 4) + (q4 & 1) * 8;
+            const int xc = a.ncls1 == 9 ? (gx == 0 ? 0 : (gx == a.W - 1 ? 2 : 1)) : 0;
+            const float *tb = (const float *)(smem + OFF2_TAB) + xc * 64 + cw * 16 + q4 * 4;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                half4 h;
+                if constexpr (IR) {
+                    const int gy = gy0 + i, yc = a.ncls1 == 9 ? (gy == 0 ? 0 : (gy == a.H - 1 ? 2 : 1)) : 0;
+                    f32x4 v = acc[i] + *(const f32x4 *)(tb + yc * 192);
+                    v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + slope1 * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                    h = __builtin_convertvector(v, half4);
+                } else {
+                    h = __builtin_elementwise_max(__builtin_convertvector(acc[i], half4), half4{0, 0, 0, 0});
+                }
+                if (edge && !(xin && (unsigned)(gy0 + i) < (unsigned)a.H)) h = half4{0, 0, 0, 0};
+                *(half4 *)(mp + i * (MW * 64)) = h;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(a.ablate & 64)) raw_barrier();                    // the intermediate tile is complete; nobody reads the x patch's halo any more
+
+        // ================= B: conv2 on the 14x14 tile, rows 7 rg .. 7 rg + 6 per pass; results in place over the x patch =================
+#pragma nounroll
+        for (int rg = 0; rg < 2; rg++) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) acc[r] = bias2;
+            if (!(a.ablate & 2))
+                conv_phase(OFF2_MID + rg * (7 * MW * 64), integral_constant<int, 7>{}, integral_constant<int, MW>{}, integral_constant<int, MID_CH>{}, w2);
+            if (a.ablate & 32) continue;
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int fr = lo & 15, q4 = lo >> 4;
+            // residual = x at the output pixel = patch pixel (row + 2, column + 2) of the chunk my couts live in; the result replaces it
+            const int g0 = (cw & 1) * 2 + (q4 >> 1);
+            char *xp = smem + OFF2_X + (cw >> 1) * P_BYTES + (q4 & 1) * 8;
+            half4 rs[7];                                        // all residual reads first: one LDS round trip, not one per row
+            int ro[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const int lin = (rg * 7 + i + 2) * PW + fr + 2;
+                ro[i] = lin * 64 + ((g0 ^ swz64(lin)) << 4);
+                rs[i] = *(const half4 *)(xp + ro[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                f32x4 v = acc[i] + __builtin_convertvector(rs[i], f32x4);
+                half4 h = __builtin_convertvector(v, half4);
+                if (a.act2 == ACT_RELU) h = __builtin_elementwise_max(h, half4{0, 0, 0, 0});
+                *(half4 *)(xp + ro[i]) = h;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(a.ablate & 64)) raw_barrier();                    // the tile is complete (all four cout fragments)
+        write_out(n, ty, tx);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of the tile are in registers (the stores themselves may fly on)
+        raw_barrier();                                          // everybody's are: the buffer is free for the next patch
+        {
+            const bool nlive = it + 1 < my_items;
+            int nn, nty, ntx;
+            decode_tile(nlive ? item + gridDim.x : 0, nn, nty, ntx);
+            if (nlive) issue_patch(nn, nty, ntx, true);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 
@@ -549,6 +801,23 @@ int conv_bb_launch(fid_ctx *ctx, const void *in, const void *w1, const float *b1
     if (Cp == 32) {                                             // four waves, two workgroups per CU
         FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb32, LDS32));
         hipLaunchKernelGGL(conv_bb32, dim3(std::min(a.n_tiles, 2 * ctx->num_cus)), dim3(NW32 * 64), LDS32, ctx->stream, a);
+        FID_HIP(hipGetLastError());
+        return FID_OK;
+    }
+    // FID_BB_V=2 (read per launch: the tests switch it): two independent four-wave workgroups per CU (conv_bb2) instead of the eight-wave form.
+    // Measured (profiles/r04/ab_runs.txt): equal alone, one-lane bench step -0.8 %, two-lane step +1.0 % -> not the default.
+    const char *bv = getenv("FID_BB_V");
+    if (bv && atoi(bv) == 2) {
+        static const int stagger = getenv("FID_BB_STAGGER") ? atoi(getenv("FID_BB_STAGGER")) : 0;
+        a.stagger = stagger;
+        const int grid2 = std::min(a.n_tiles, 2 * ctx->num_cus);
+        if (ncls1 == 9 || act1 == ACT_PRELU) {
+            FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb2<true>, LDS2_BYTES));
+            hipLaunchKernelGGL(conv_bb2<true>, dim3(grid2), dim3(NW2 * 64), LDS2_BYTES, ctx->stream, a);
+        } else {
+            FID_TRY(ensure_dyn_lds(ctx, (const void *)conv_bb2<false>, LDS2_BYTES));
+            hipLaunchKernelGGL(conv_bb2<false>, dim3(grid2), dim3(NW2 * 64), LDS2_BYTES, ctx->stream, a);
+        }
         FID_HIP(hipGetLastError());
         return FID_OK;
     }

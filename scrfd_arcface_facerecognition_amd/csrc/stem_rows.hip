@@ -272,10 +272,9 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
                     const half8 pf = __builtin_bit_cast(half8, pv[i]);
 #pragma unroll
                     for (int f = 0; f < 2; f++) {
-                        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[f], pf, c, 0, 0, 0);
-                        half4 h = __builtin_elementwise_max(__builtin_convertvector(c + bias0[f], half4), half4{0, 0, 0, 0});   // ReLU after the rounding: same result
-                        if (!inside[i]) h = half4{0, 0, 0, 0};
+                        const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[f], pf, bias0[f], 0, 0, 0);      // (the bias is the C operand: no add afterwards)
+                        half4 h = __builtin_elementwise_max(__builtin_convertvector(c, half4), half4{0, 0, 0, 0});   // ReLU after the rounding: same result
+                        if (!interior && !inside[i]) h = half4{0, 0, 0, 0};
                         if (lin[i] >= 0) *(half4 *)(smem + OFF_C0 + lin[i] * 64 + (((f * 2 + (fq >> 1)) ^ swz64(lin[i])) << 4) + (fq & 1) * 8) = h;
                     }
                 }
@@ -289,19 +288,21 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
             const int r_lo = g1 * ROWS1;
             int pb[2][4];
             make_pb(((r_lo * PW0) >> 1) & 3, OFF_C0 + r_lo * PW0 * 64, pb);
+            {
+                const f32x4 bias1 = *(const f32x4 *)(sB + 32 + f1 * 16 + fq * 4);      // the accumulators start from the bias: no add in the epilogue
 #pragma unroll
-            for (int r = 0; r < ROWS1; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < ROWS1; r++) acc[r] = bias1;
+            }
             conv_rows(pb, integral_constant<int, ROWS1>{}, integral_constant<int, PW0>{}, w1f);
             int lo = lane;
             asm volatile("" : "+v"(lo));
             const int fr = lo & 15, q4 = lo >> 4;
-            const f32x4 bias1 = *(const f32x4 *)(sB + 32 + f1 * 16 + q4 * 4);
             const bool xin = fr < CW1 && (unsigned)(ox0 + 1 + fr) < (unsigned)a.W1;
             char *cp = smem + OFF_C1 + (r_lo * PW1 + fr) * 64 + (((f1 * 2 + (q4 >> 1)) ^ swz64(fr)) << 4) + (q4 & 1) * 8;
 #pragma unroll
             for (int i = 0; i < ROWS1; i++) {
                 if (r_lo + i >= R1) continue;                      // (wave-uniform: the second row group of an odd row count)
-                half4 h = __builtin_elementwise_max(__builtin_convertvector(acc[i] + bias1, half4), half4{0, 0, 0, 0});
+                half4 h = __builtin_elementwise_max(__builtin_convertvector(acc[i], half4), half4{0, 0, 0, 0});
                 if (!interior && !(xin && (unsigned)(oy0 + 1 + r_lo + i) < (unsigned)a.H1)) h = half4{0, 0, 0, 0};
                 *(half4 *)(cp + i * (PW1 * 64)) = h;
             }
@@ -314,17 +315,19 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
             const int r_lo = g2 * PY;                              // (a multiple of 8 rows x 16 pixels: no swizzle rotation)
             int pb[2][4];
             make_pb(0, OFF_C1 + r_lo * PW1 * 64, pb);
+            {
+                const f32x4 bias2 = *(const f32x4 *)(sB + 64 + f2 * 16 + fq * 4);
 #pragma unroll
-            for (int r = 0; r < ROWS2; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < ROWS2; r++) acc[r] = bias2;
+            }
             conv_rows(pb, integral_constant<int, ROWS2>{}, integral_constant<int, PW1>{}, w2f);
             int lo = lane;
             asm volatile("" : "+v"(lo));
             const int fr = lo & 15, q4 = lo >> 4;
-            const f32x4 bias2 = *(const f32x4 *)(sB + 64 + f2 * 16 + q4 * 4);
             const bool xin = fr < CW2 && (unsigned)(ox0 + 2 + fr) < (unsigned)a.W1;
             const int gy0 = oy0 + 2 + r_lo;
-            // The pool runs on the RAW sums: max commutes with "+ bias" (one bias per channel) and with ReLU and the fp16 rounding (both
-            // monotone), so relu(round(max + bias)) = max of the rounded, activated values.  Positions outside the map must not win: they
+            // The pool runs on the fp32 sums (bias included: the accumulators started from it): max commutes with ReLU and the fp16 rounding
+            // (both monotone), so relu(round(max)) = max of the rounded, activated values.  Positions outside the map must not win: they
             // become -inf (every window holds a real pixel); only tiles on the map border have any.
             if (!interior) {
                 const float ninf = -__builtin_inff();
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
                     const float v = fmaxf(fmaxf(acc[2 * p][e], acc[2 * p + 1][e]), acc[2 * p + 2][e]);     // (v_max3_f32)
                     m[e] = fmaxf(fmaxf(v, row_shl<1>(v)), row_shl<2>(v));
                 }
-                const half4 h = __builtin_elementwise_max(__builtin_convertvector(m + bias2, half4), half4{0, 0, 0, 0});
+                const half4 h = __builtin_elementwise_max(__builtin_convertvector(m, half4), half4{0, 0, 0, 0});
                 if (st) *(half4 *)(sp + p * (PXT * ROWB2)) = h;
             }
         }

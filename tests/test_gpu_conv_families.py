@@ -208,7 +208,7 @@ def test_fused_shortcut_stride2(ctx, monkeypatch, fuse, hw, planes, batch):
 # a residual BasicBlock on 64 stored channels as ONE launch (lower.py pattern; conv_bb.hip: 14x14 output tiles, the intermediate map in LDS,
 # the residual from the input patch): fused and unfused lowering against the oracle -- maps that are / are not multiples of 14, maps smaller
 # than a tile, one image, two chained blocks (the second walks its items in the other direction), both activations after the add
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("fuse", [True, "v2", False])      # "v2": conv_bb2 (two four-wave workgroups per CU, the tile finished in place; FID_BB_V=2)
 # ("ir": IResNet's form -- BN - conv - BN - PReLU - conv - BN, + input -- conv1 then carries 9 border-class bias rows and PReLU slopes)
 @pytest.mark.parametrize("hw,planes,batch,act2", [((56, 84), 56, 3, "relu"), ((37, 45), 64, 2, "relu"), ((12, 20), 56, 5, "none"), ((160, 160), 56, 1, "relu"),
                                                   ((29, 16), 40, 4, "relu"), ((56, 56), 64, 3, "ir"), ((23, 31), 64, 2, "ir"), ((14, 14), 64, 5, "ir"),
@@ -219,6 +219,13 @@ def test_fused_basic_block(ctx, monkeypatch, fuse, hw, planes, batch, act2):
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     if not fuse:
         monkeypatch.setenv("FID_NO_BB_FUSE", "1")
+    if fuse == "v2":
+        if planes <= 32:
+            pytest.skip("conv_bb2 is the 64-channel kernel")
+        monkeypatch.setenv("FID_BB_V", "2")
+    else:
+        monkeypatch.delenv("FID_BB_V", raising=False)
+    fuse = bool(fuse)
     net = Net("t", hw, 127.5, 1.0 / 128.0)
     ir = act2 == "ir"
     a1 = dict(act="prelu", pre_bn=True) if ir else dict(act="relu")
