@@ -85,9 +85,11 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
     constexpr int IN_BYTES = (RI * RS * 2 + 16 + 255) / 256 * 256;
     constexpr int C0_BYTES = (R0 + 1) * PW0 * 64, C1_BYTES = (R1 + 1) * PW1 * 64 + 256, STG_BYTES = PY * PXT * ROWB2;
     constexpr int OFF_IN = 0, OFF_C0 = IN_BYTES, OFF_C1 = OFF_C0 + C0_BYTES, OFF_STG = OFF_C1 + C1_BYTES, OFF_BIAS = OFF_STG + STG_BYTES;
+    constexpr int MF0 = (NF0 + 3) / 4;                             // conv0 fragments per wave
+    constexpr int OFF_TAB = OFF_BIAS + 512, TAB_DW = MF0 + 4;      // per-thread constants of conv0's gather ([entry][thread] dwords), see below
     constexpr int ZD = RI * RS / 2;                                // dword index of the zero dword behind the patch
-    static_assert(PY % 2 == 0 && OFF_BIAS + 512 <= 80 * 1024, "two workgroups per CU");
-    static_assert(PY != 6 || STEM_WPS < 3 || OFF_BIAS + 512 <= 53 * 1024, "three workgroups per CU");
+    static_assert(PY % 2 == 0 && OFF_TAB + TAB_DW * 1024 <= 80 * 1024, "two workgroups per CU");
+    static_assert(PY != 6 || STEM_WPS < 3 || OFF_TAB + TAB_DW * 1024 <= 53 * 1024, "three workgroups per CU");
     constexpr int NDW = RI * DROW, DPT = (NDW + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -212,6 +214,25 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
     };
     using std::integral_constant;
 
+    // conv0's fragments (wave, wave + 4, ...) are the same pixels of every tile: the window's LDS byte address and the lane's result address
+    // (cout fragment 0; fragment 1 = ^ 32: the swizzled 16-byte group index differs in bit 1) are computed ONCE -- per tile they cost ~35 VALU
+    // instructions per fragment (division by 17, swizzle, bounds), a quarter of this stage.  They live in a per-thread LDS table, not in
+    // registers (the matrix phases have none to spare: held in registers they are spilled to scratch).  Lanes past the region (the last
+    // fragment's tail) gather pixel N0 - 1 and write to the slack row R0 of the map, which only feeds conv1's discarded row.
+    static_assert(OFF_C0 + C0_BYTES < 65536 && IN_BYTES < 65536, "both addresses of a fragment share one dword");
+    unsigned *sT = (unsigned *)(smem + OFF_TAB) + tid;
+#pragma unroll
+    for (int i = 0; i < MF0; i++) {
+        const int qd = (wave + 4 * i) * 16 + frow, q = qd < N0 ? qd : N0 - 1;
+        const int y = q / CW0, x = q - y * CW0;
+        const int lin = qd < N0 ? y * PW0 + x : R0 * PW0 + frow;
+        const int ga = OFF_IN + (y * RS + 3 * x + 1) * 4;
+        const int sa = OFF_C0 + lin * 64 + ((((fq >> 1)) ^ swz64(lin)) << 4) + (fq & 1) * 8;
+        sT[i * 256] = (unsigned)ga | ((unsigned)sa << 16);         // gather address | result address << 16
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) sT[(MF0 + j) * 256] = (unsigned)(rel[j] * 4);
+
     int tile = blockIdx.x;
     if (tile < a.n_tiles) prefetch(tile);
     // The two workgroups of a CU run the same program on tiles of equal cost: started together they stay in lock-step -- both in a matrix
@@ -239,43 +260,57 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
 
         // ---------------- S1: conv0 (K = 27 in 30 slots), stride 2: flattened fragments wave, wave + 4, ... ----------------
         if (!(a.ablate & 1)) {
-            // all gathers of the wave's fragments first, then the MFMAs and epilogues: one LDS round trip per tile instead of one per fragment
-            constexpr int MF0 = (NF0 + 3) / 4, FB = 3;             // fragments per wave; gathered FB at a time
-            const unsigned *ip = (const unsigned *)(smem + OFF_IN);
-            int lo = lane;
-            asm volatile("" : "+v"(lo));                           // opaque lane id: the per-fragment addresses are recomputed per tile, not kept in registers across the loop
-            const int frow = lo & 15, fq = lo >> 4;
+            // FB fragments at a time: their gathers (one LDS round trip), their MFMAs (the bias is the C operand), then their epilogues --
+            // an MFMA's result is not touched before the batch's other MFMAs have issued
+            constexpr int FB = 3;
+            int lt = tid;
+            asm volatile("" : "+v"(lt));                           // opaque: the table address is formed here, per tile
+            const unsigned *tp = (const unsigned *)(smem + OFF_TAB) + lt;
+            unsigned g_as[MF0];
+            int relb[4];
+#pragma unroll
+            for (int i = 0; i < MF0; i++) g_as[i] = tp[i * 256];
+#pragma unroll
+            for (int j = 0; j < 4; j++) relb[j] = (int)tp[(MF0 + j) * 256];
             f32x4 bias0[2];
 #pragma unroll
             for (int f = 0; f < 2; f++) bias0[f] = *(const f32x4 *)(sB + f * 16 + fq * 4);
 #pragma unroll
             for (int i0 = 0; i0 < MF0; i0 += FB) {
                 u32x4 pv[FB];
-                int lin[FB];
-                bool inside[FB];
 #pragma unroll
                 for (int i = 0; i < FB; i++) {
-                    const int fi = wave + 4 * (i0 + i);
-                    const int qd = fi * 16 + frow, q = qd < N0 ? qd : N0 - 1;
-                    const int y = q / CW0, x = q - y * CW0;
-                    const int bdw = y * RS + 3 * x + 1;            // dword of the window's first (weight-0) half: patch row 2y, half 6x + 2
-                    pv[i][0] = ip[bdw + rel[0]];
-                    pv[i][1] = ip[bdw + rel[1]];
-                    pv[i][2] = ip[bdw + rel[2]];
-                    pv[i][3] = ip[fq == 3 ? ZD : bdw + rel[3]];
-                    inside[i] = qd < N0 && (unsigned)(oy0 + y) < (unsigned)a.H1 && (unsigned)(ox0 + x) < (unsigned)a.W1;
-                    lin[i] = qd < N0 ? y * PW0 + x : -1;
+                    if (i0 + i >= MF0) continue;
+                    const int ga = (int)(g_as[i0 + i] & 0xFFFFu);
+                    pv[i][0] = *(const unsigned *)(smem + (ga + relb[0]));
+                    pv[i][1] = *(const unsigned *)(smem + (ga + relb[1]));
+                    pv[i][2] = *(const unsigned *)(smem + (ga + relb[2]));
+                    pv[i][3] = *(const unsigned *)(smem + (fq == 3 ? OFF_IN + ZD * 4 : ga + relb[3]));      // (quarter 3: the zero dword behind the patch)
                 }
+                f32x4 c[FB][2];
 #pragma unroll
                 for (int i = 0; i < FB; i++) {
                     if (i0 + i >= MF0 || wave + 4 * (i0 + i) >= NF0) continue;     // (wave-uniform)
                     const half8 pf = __builtin_bit_cast(half8, pv[i]);
 #pragma unroll
+                    for (int f = 0; f < 2; f++) c[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[f], pf, bias0[f], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < FB; i++) {
+                    if (i0 + i >= MF0 || wave + 4 * (i0 + i) >= NF0) continue;
+                    bool inside = true;
+                    if (!interior) {                               // (wave-uniform: border tiles only) positions outside the stride-2 map are conv1's zero padding
+                        int lo = lane;
+                        asm volatile("" : "+v"(lo));               // opaque: computed here, on the few border tiles, not hoisted out of the tile loop (and spilled)
+                        const int qd = (wave + 4 * (i0 + i)) * 16 + (lo & 15), q = qd < N0 ? qd : N0 - 1;
+                        const int y = q / CW0, x = q - y * CW0;
+                        inside = (unsigned)(oy0 + y) < (unsigned)a.H1 && (unsigned)(ox0 + x) < (unsigned)a.W1;
+                    }
+#pragma unroll
                     for (int f = 0; f < 2; f++) {
-                        const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[f], pf, bias0[f], 0, 0, 0);      // (the bias is the C operand: no add afterwards)
-                        half4 h = __builtin_elementwise_max(__builtin_convertvector(c, half4), half4{0, 0, 0, 0});   // ReLU after the rounding: same result
-                        if (!interior && !inside[i]) h = half4{0, 0, 0, 0};
-                        if (lin[i] >= 0) *(half4 *)(smem + OFF_C0 + lin[i] * 64 + (((f * 2 + (fq >> 1)) ^ swz64(lin[i])) << 4) + (fq & 1) * 8) = h;
+                        half4 h = __builtin_elementwise_max(__builtin_convertvector(c[i][f], half4), half4{0, 0, 0, 0});   // ReLU after the rounding: same result
+                        if (!inside) h = half4{0, 0, 0, 0};
+                        *(half4 *)(smem + ((g_as[i0 + i] >> 16) ^ (f * 32))) = h;
                     }
                 }
             }
@@ -685,7 +720,8 @@ int launch_roles(fid_ctx *ctx, StemRArgs &a) {
 template <int C2P, int PY>
 int launch_rows(fid_ctx *ctx, StemRArgs &a) {
     constexpr int R2 = 2 * PY + 1, R1 = R2 + 2, R0 = R2 + 4, RI = 2 * R0 + 1;
-    constexpr int lds = (RI * RS * 2 + 16 + 255) / 256 * 256 + (R0 + 1) * PW0 * 64 + (R1 + 1) * PW1 * 64 + 256 + PY * PXT * C2P * 2 + 512;
+    constexpr int MF0 = ((R0 * CW0 + 15) / 16 + 3) / 4;           // + the per-thread table of conv0's gather: (MF0 + 4) dwords x 256 threads
+    constexpr int lds = (RI * RS * 2 + 16 + 255) / 256 * 256 + (R0 + 1) * PW0 * 64 + (R1 + 1) * PW1 * 64 + 256 + PY * PXT * C2P * 2 + 512 + (MF0 + 4) * 1024;
     a.tiles_x = cdiv(a.Wp, PXT); a.tiles_y = cdiv(a.Hp, PY);
     a.n_tiles = (a.n_tiles) * a.tiles_x * a.tiles_y;              // (n_tiles holds the batch size on entry)
     FID_TRY(ensure_dyn_lds(ctx, (const void *)scrfd_stem_rows<C2P, PY>, lds));
