@@ -136,20 +136,51 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
     // 3 bytes of lead-in): rows and the window are dword aligned (the frame width is a multiple of 4), so a dword is inside or outside as a whole
     unsigned pre[DPT];
     unsigned pre_ok = 0;
+    bool pre_int = false;                                          // the prefetched patch lies inside the frame: no dword to clear (wave-uniform)
+    // my dword i of a patch = patch row pr, dword dc of its window: its byte offset from the window's first byte is the same for every tile
+    // (threads past the patch's last dword: far out of range).  A tile's loads are buffer loads on ITS frame (base and size in SGPRs):
+    // one add per dword, and rows above / below the frame are out of range by themselves and arrive as 0.
+    const int rowbytes = a.W * 3;
+    int v_rel[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; i++) {
+        const int d = tid + 256 * i;
+        const int pr = d / DROW, dc = d - pr * DROW;
+        v_rel[i] = d < NDW ? pr * rowbytes + dc * 4 : 0x7FFF0000;
+        asm volatile("" : "+v"(v_rel[i]));
+    }
     auto prefetch = [&](int tile) {
         int n, ty, tx;
         decode(tile, n, ty, tx);
-        const int iy0 = 4 * PY * ty - 7, bx0 = 72 * tx - 24, rowbytes = a.W * 3;
-        const uint8_t *base = a.img + (size_t)n * a.H * rowbytes;
-        pre_ok = 0;
+        const int iy0 = 4 * PY * ty - 7, bx0 = 72 * tx - 24;
+        const auto rs_img = __builtin_amdgcn_make_buffer_rsrc((void *)(a.img + (size_t)n * a.H * rowbytes), 0, a.H * rowbytes, 0x00020000);
+        const int s_off = iy0 * rowbytes + bx0;
+        const bool xin_all = bx0 >= 0 && bx0 + DROW * 4 <= rowbytes;       // every dword of the window lies inside the frame's rows
+        pre_int = xin_all && iy0 >= 0 && iy0 + RI <= a.H;
+        if (xin_all) {
 #pragma unroll
-        for (int i = 0; i < DPT; i++) {
-            const int d = tid + 256 * i;
-            const int pr = d / DROW, dc = d - pr * DROW;
-            const int iy = iy0 + pr, bx = bx0 + dc * 4;
-            const bool in = d < NDW && (unsigned)iy < (unsigned)a.H && bx >= 0 && bx + 4 <= rowbytes;
-            pre[i] = in ? *(const unsigned *)(base + (size_t)iy * rowbytes + bx) : 0u;
-            pre_ok |= in ? (1u << i) : 0u;
+            for (int i = 0; i < DPT; i++) pre[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_img, v_rel[i] + s_off, 0, 0);
+        } else {                                                    // a window that sticks out of the rows (left / right tile columns): per-dword test
+#pragma unroll
+            for (int i = 0; i < DPT; i++) {
+                int d = tid + 256 * i;
+                asm volatile("" : "+v"(d));                        // (computed here, not hoisted into registers)
+                const int pr = d / DROW, bx = bx0 + (d - pr * DROW) * 4;
+                pre[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_img, (bx >= 0 && bx + 4 <= rowbytes) ? v_rel[i] + s_off : 0x7FFF0000, 0, 0);
+            }
+        }
+        pre_ok = 0xFFFFFFFFu;
+        if (!pre_int) {                                             // which dwords are real pixels (a real 0 is -255, the blob's padding is 0)
+            pre_ok = 0;
+#pragma unroll
+            for (int i = 0; i < DPT; i++) {
+                int d = tid + 256 * i;
+                asm volatile("" : "+v"(d));
+                const int pr = d / DROW, dc = d - pr * DROW;
+                const int iy = iy0 + pr, bx = bx0 + dc * 4;
+                const bool in = d < NDW && (unsigned)iy < (unsigned)a.H && bx >= 0 && bx + 4 <= rowbytes;
+                pre_ok |= in ? (1u << i) : 0u;
+            }
         }
     };
     auto commit = [&]() {
@@ -164,7 +195,7 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
                 h[1] = (_Float16)fmaf((float)((v >> 8) & 0xFF), 2.f, -255.f);
                 h[2] = (_Float16)fmaf((float)((v >> 16) & 0xFF), 2.f, -255.f);
                 h[3] = (_Float16)fmaf((float)(v >> 24), 2.f, -255.f);
-                if (!((pre_ok >> i) & 1u)) h = half4{0, 0, 0, 0};    // outside the frame: the blob's zero padding (a real pixel 0 is -255)
+                if (!pre_int && !((pre_ok >> i) & 1u)) h = half4{0, 0, 0, 0};    // outside the frame: the blob's zero padding (a real pixel 0 is -255)
                 *(half4 *)(smem + OFF_IN + (pr * RS + dc * 4) * 2) = h;
             }
         }
