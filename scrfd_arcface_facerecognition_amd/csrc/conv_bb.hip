@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv_bb(const BBArgs a) {
                 if constexpr (IR) {
                     const int gy = gy0 + i, yc = a.ncls1 == 9 ? (gy == 0 ? 0 : (gy == a.H - 1 ? 2 : 1)) : 0;
                     f32x4 v = acc[i] + *(const f32x4 *)(tb + yc * 192);
-                    v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + slope1 * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                    v = __builtin_elementwise_fma(slope1, __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f}), __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}));   // (one rounding: max + slope * min)
                     h = __builtin_convertvector(v, half4);
                 } else {
                     h = __builtin_elementwise_max(__builtin_convertvector(acc[i], half4), half4{0, 0, 0, 0});
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) conv_bb2(const BBArgs a) {
                 if constexpr (IR) {
                     const int gy = gy0 + i, yc = a.ncls1 == 9 ? (gy == 0 ? 0 : (gy == a.H - 1 ? 2 : 1)) : 0;
                     f32x4 v = acc[i] + *(const f32x4 *)(tb + yc * 192);
-                    v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}) + slope1 * __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f});
+                    v = __builtin_elementwise_fma(slope1, __builtin_elementwise_min(v, f32x4{0.f, 0.f, 0.f, 0.f}), __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f}));   // (one rounding: max + slope * min)
                     h = __builtin_convertvector(v, half4);
                 } else {
                     h = __builtin_elementwise_max(__builtin_convertvector(acc[i], half4), half4{0, 0, 0, 0});
