@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
     constexpr int C0_BYTES = (R0 + 1) * PW0 * 64, C1_BYTES = (R1 + 1) * PW1 * 64 + 256, STG_BYTES = PY * PXT * ROWB2;
     constexpr int OFF_IN = 0, OFF_C0 = IN_BYTES, OFF_C1 = OFF_C0 + C0_BYTES, OFF_STG = OFF_C1 + C1_BYTES, OFF_BIAS = OFF_STG + STG_BYTES;
     constexpr int MF0 = (NF0 + 3) / 4;                             // conv0 fragments per wave
-    constexpr int OFF_TAB = OFF_BIAS + 512, TAB_DW = MF0 + 4;      // per-thread constants of conv0's gather ([entry][thread] dwords), see below
+    constexpr int OFF_TAB = OFF_BIAS + 512, TAB_DW = MF0;      // per-thread constants of conv0's gather ([entry][thread] dwords), see below
     constexpr int ZD = RI * RS / 2;                                // dword index of the zero dword behind the patch
     static_assert(PY % 2 == 0 && OFF_TAB + TAB_DW * 1024 <= 80 * 1024, "two workgroups per CU");
     static_assert(PY != 6 || STEM_WPS < 3 || OFF_TAB + TAB_DW * 1024 <= 53 * 1024, "three workgroups per CU");
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
         sT[i * 256] = (unsigned)ga | ((unsigned)sa << 16);         // gather address | result address << 16
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) sT[(MF0 + j) * 256] = (unsigned)(rel[j] * 4);
+    for (int j = 0; j < 4; j++) { rel[j] *= 4; asm volatile("" : "+v"(rel[j])); }      // (byte offsets of the lane's four window dwords: four registers, as before)
 
     int tile = blockIdx.x;
     if (tile < a.n_tiles) prefetch(tile);
@@ -298,11 +298,9 @@ __global__ void __launch_bounds__(256, PY == 6 ? STEM_WPS : 2) scrfd_stem_rows(c
             asm volatile("" : "+v"(lt));                           // opaque: the table address is formed here, per tile
             const unsigned *tp = (const unsigned *)(smem + OFF_TAB) + lt;
             unsigned g_as[MF0];
-            int relb[4];
 #pragma unroll
             for (int i = 0; i < MF0; i++) g_as[i] = tp[i * 256];
-#pragma unroll
-            for (int j = 0; j < 4; j++) relb[j] = (int)tp[(MF0 + j) * 256];
+            const int (&relb)[4] = rel;
             f32x4 bias0[2];
 #pragma unroll
             for (int f = 0; f < 2; f++) bias0[f] = *(const f32x4 *)(sB + f * 16 + fq * 4);
@@ -751,8 +749,8 @@ int launch_roles(fid_ctx *ctx, StemRArgs &a) {
 template <int C2P, int PY>
 int launch_rows(fid_ctx *ctx, StemRArgs &a) {
     constexpr int R2 = 2 * PY + 1, R1 = R2 + 2, R0 = R2 + 4, RI = 2 * R0 + 1;
-    constexpr int MF0 = ((R0 * CW0 + 15) / 16 + 3) / 4;           // + the per-thread table of conv0's gather: (MF0 + 4) dwords x 256 threads
-    constexpr int lds = (RI * RS * 2 + 16 + 255) / 256 * 256 + (R0 + 1) * PW0 * 64 + (R1 + 1) * PW1 * 64 + 256 + PY * PXT * C2P * 2 + 512 + (MF0 + 4) * 1024;
+    constexpr int MF0 = ((R0 * CW0 + 15) / 16 + 3) / 4;           // + the per-thread table of conv0's gather: MF0 dwords x 256 threads
+    constexpr int lds = (RI * RS * 2 + 16 + 255) / 256 * 256 + (R0 + 1) * PW0 * 64 + (R1 + 1) * PW1 * 64 + 256 + PY * PXT * C2P * 2 + 512 + MF0 * 1024;
     a.tiles_x = cdiv(a.Wp, PXT); a.tiles_y = cdiv(a.Hp, PY);
     a.n_tiles = (a.n_tiles) * a.tiles_x * a.tiles_y;              // (n_tiles holds the batch size on entry)
     FID_TRY(ensure_dyn_lds(ctx, (const void *)scrfd_stem_rows<C2P, PY>, lds));
