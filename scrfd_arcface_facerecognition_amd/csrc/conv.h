@@ -92,7 +92,7 @@ int conv_pcr_launch(fid_ctx *ctx, const ConvArgs &a);
 // conv_wr.hip (generation 9): weights in registers, waves split by cout, a pair of tiles x 128 couts per item; needs w_alt (kind 2)
 bool conv_wr_applicable(const ConvArgs &a);
 bool conv_wr_resident_ok(const ConvArgs &a);
-int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident, int ring);
+int conv_wr_launch(fid_ctx *ctx, const ConvArgs &a, int nt, int cb, int resident, int ring, bool strip = false);   // strip: STRIP tiles (ns = 8 streaming, 9 resident)
 
 // mbf_block.hip: MobileFaceNet's bottleneck (1x1 -> depthwise 3x3 / stride 1 | 2 -> 1x1 [+ input]) in one launch, the expanded maps in LDS
 bool mbf_block_applicable(int H, int W, int Cin_p, int Gp, int Cout_p, int stride, bool res);
@@ -102,8 +102,13 @@ int mbf_block_launch(fid_ctx *ctx, const void *x, const void *w1, const float *b
 // conv_ks.hip (generation 9, ns = 6): conv3x3_wr's one-tile x 64-cout item with the K axis split over two wave groups (few tiles: one item per CU); needs w_alt (kind 2)
 bool conv_ks_applicable(const ConvArgs &a);
 bool conv_ks_mosaic(const ConvArgs &a);      // 7x7 maps: four images share a 16x16 tile
-int conv_ks_launch(fid_ctx *ctx, const ConvArgs &a, int per_wg = 1);   // per_wg = 2: two items per workgroup (plan tile 512)
-int conv_ks_items(const ConvArgs &a);                                   // work items (tiles x 64-cout blocks) of the launch
+int conv_ks_launch(fid_ctx *ctx, const ConvArgs &a, int per_wg = 1, bool strip = false);   // per_wg = 2: two items per workgroup (plan tile 512)
+int conv_ks_items(const ConvArgs &a, bool strip = false);               // work items (tiles x 64-cout blocks) of the launch
+// STRIP tiles (round 5, generation 9 with ns = 7 / 8 / 9): x-packed pixel fragments -- a tile is TH rows x 16 consecutive columns of the strip
+// formed by the rows of all images side by side (8 images x 14 columns = 7 exact fragments); conv_ks.hip explains the addressing
+bool conv_strip_ok(const ConvArgs &a);       // every 16-column strip tile crosses at most one image boundary
+int conv_strip_rows(const ConvArgs &a);      // tile rows of a STRIP launch (10 | 14 | 16)
+bool conv_ks_strip_applicable(const ConvArgs &a);
 
 // conv_s2.hip (generation 10): 3x3 / stride 2 with parity-plane patches and resident weights (64 / 96 input channels); needs w_alt (kind 2)
 bool conv_s2_applicable(const ConvArgs &a);

@@ -869,10 +869,17 @@ static std::vector<ConvPlan> conv_candidates_all(const ConvArgs &a, int num_cus,
         d.bm = 256; d.bn = 64; out.push_back(d);       // one tile x 64 couts (few tiles: more items)
         d.ns = 4; out.push_back(d); d.ns = 0;          // ... with the patches three steps ahead (small batches: one workgroup per CU)
         if (conv_wr_resident_ok(a)) { d.bm = 256; d.bn = a.Cout_p; d.ns = 1; out.push_back(d); }   // the layer's weights resident in registers
+        if (conv_strip_ok(a)) {                        // the same on x-packed STRIP tiles (round 5): ns = 8 streaming, 9 resident
+            d.ns = 8; d.bm = 512; d.bn = 128; out.push_back(d);
+            d.bm = 256; d.bn = 64; out.push_back(d);
+            if (conv_wr_resident_ok(a)) { d.bm = 256; d.bn = a.Cout_p; d.ns = 9; out.push_back(d); }
+            d.ns = 0;
+        }
         if (conv_ks_applicable(a)) {                   // one tile x 64 couts, the K axis split over two wave groups (conv_ks.hip)
             d.bm = 256; d.bn = 64; d.ns = 6; out.push_back(d);
             const int items = conv_ks_items(a);        // few items: also on half the CUs with two or more items per workgroup (tile 512; fewer CUs for longer, FID_TUNE_SHARE)
             if (items >= 2 && items <= 2 * num_cus) { d.bm = 512; out.push_back(d); }
+            if (conv_ks_strip_applicable(a)) { d.bm = 256; d.bn = 64; d.ns = 7; out.push_back(d); }   // ... on x-packed STRIP tiles
         }
     }
     else if (conv_ks_applicable(a)) {                  // 7x7 maps: four images per 16x16 tile (conv_ks.hip, MOSAIC)
@@ -956,8 +963,10 @@ float conv_plan_cu_share(const ConvArgs &a, const ConvPlan &plan, int num_cus) {
     long long wgs = -1;
     if (plan.gen == 1 || plan.gen == 2 || plan.gen == 11) wgs = (long long)cdiv(a.M, plan.bm) * cdiv(a.Cout_p, plan.bn) * std::max(1, plan.ksplit);
     else if (plan.gen == 9 && plan.ns == 6) wgs = plan.bm >= 512 ? std::min(cdiv(conv_ks_items(a), 2), num_cus / 2) : conv_ks_items(a);
-    else if (plan.gen == 9 && plan.ns != 1) {
-        const long long tiles = (long long)(a.M / (a.Ho * a.Wo)) * cdiv(a.Ho, 14) * cdiv(a.Wo, 14);      // (14 / 16-row tiles: the smaller count)
+    else if (plan.gen == 9 && plan.ns == 7) wgs = conv_ks_items(a, true);
+    else if (plan.gen == 9 && plan.ns != 1 && plan.ns != 9) {
+        const long long tiles = plan.ns == 8 ? (long long)cdiv((a.M / (a.Ho * a.Wo)) * a.Wo, 16) * cdiv(a.Ho, 16)
+                                             : (long long)(a.M / (a.Ho * a.Wo)) * cdiv(a.Ho, 14) * cdiv(a.Wo, 14);      // (14 / 16-row tiles: the smaller count)
         wgs = cdiv((int)tiles, plan.bm / 256) * cdiv(a.Cout_p, plan.bn);
     }
     if (wgs < 0 || wgs >= num_cus) return 1.f;
@@ -974,6 +983,8 @@ int conv_launch(fid_ctx *ctx, ConvArgs a, const ConvPlan &plan) {
     if (plan.gen == 10) return conv_s2_launch(ctx, a);
     if (plan.gen == 11) return conv_gw_launch(ctx, a, plan.bm, plan.bn);
     if (plan.gen == 9 && plan.ns == 6) return conv_ks_launch(ctx, a, plan.bm / 256);
+    if (plan.gen == 9 && plan.ns == 7) return conv_ks_launch(ctx, a, 1, true);
+    if (plan.gen == 9 && (plan.ns == 8 || plan.ns == 9)) return conv_wr_launch(ctx, a, plan.bm / 256, plan.bn, plan.ns == 9, 2, true);
     if (plan.gen == 9) return conv_wr_launch(ctx, a, plan.bm / 256, plan.bn, plan.ns == 1, plan.ns == 4 ? 4 : 2);
     a.T = a.kh * a.kw;
     FID_REQUIRE(a.T >= 1 && a.T <= 25, "conv: %dx%d taps unsupported", a.kh, a.kw);

@@ -11,6 +11,14 @@
 // does not finish to its partner (rows [0, TH/2) are finished by kg = 0, the rest by kg = 1), adds what it receives, applies bias / residual /
 // activation to ITS rows and stages them; all 8 waves write the tile out as 16-byte rows.  The fp32 sum order differs from conv3x3_wr's
 // (chunk pairs are summed inside a group, the two groups last): a different kernel pick, like every other family.
+//
+// STRIP (round 5; MODE bit 2): x-packed pixel fragments.  The 16 lanes of an MFMA pixel operand are 16 per-lane LDS addresses -- nothing forces
+// them into one image.  The rows of ALL images of the batch laid side by side form a strip of B * W columns, and a tile is TH rows x 16 CONSECUTIVE
+// STRIP COLUMNS: on a 14-wide map eight images are seven exact fragments (a 14-column tile leaves lanes 14, 15 idle: 1.14 x the matrix work), on
+// 28 / 56 / 112 / 20 / 40-wide maps likewise.  A tile crosses at most one image boundary (host-checked): lanes behind it belong to the next image
+// and read one patch position further right, so that ONE shared zero column (the right padding of image A = the left padding of image B) sits
+// between the two images in the patch (PW = 19).  Row-sharing, the tap order and every counted wait are unchanged; what changes is the
+// piece -> pixel mapping of the patch fetch, a per-item lane shift in the fragment addresses, and the lane -> pixel mapping of the epilogue.
 #include <type_traits>
 
 #include "conv.h"
@@ -26,7 +34,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB = 0x7FFFFFF0u;
-constexpr int PW = 18, CK = 32;                                   // patch width, channels per chunk
+constexpr int CK = 32;                                            // channels per chunk (patch width: 18 positions, 19 with STRIP)
 constexpr int NW = 4, KS = 2, NWT = NW * KS, CBW = NW * 16;       // cout fragments, K halves, waves, couts per item
 constexpr int ROWB = CBW * 2, CPX = ROWB / 16;                    // bytes / 16-byte chunks of a staged pixel row
 
@@ -47,7 +55,8 @@ struct KSArgs {
     unsigned in_bytes, out_bytes, w_bytes;
     int ncls;             // bias classes: 9 with CF_BORDER, 1 with a plain bias, 0 without
     int rev;              // ConvArgs::rev
-    int n_img;            // images (MOSAIC: the faces four of which share a tile)
+    int n_img;            // images (MOSAIC: the faces four of which share a tile; STRIP: the strip's images)
+    int tiles_y;          // STRIP: tile rows; tile t = (strip tile t / tiles_y, tile row t % tiles_y), d_tx divides by tiles_y, d_tpi by W
     int ablate;           // FID_KS_ABLATE timing experiments (wrong results): 1 no step barrier, 2 no patch pieces, 4 no weight reloads, 8 no epilogue, 16 no matrix work
 };
 
@@ -55,10 +64,13 @@ struct KSArgs {
 // [8r, 8r + 7) x [8c, 8c + 7); tile row / column 7 and 15 are zero gutters (the zero padding between neighbours: never fetched, computed and
 // dropped), so one 16-pixel matrix column carries two images and an item's 64 x 9 Cin weights serve four images instead of one.
 // MODE 2 (the map is one tile high, H = TH -- IResNet's 14x14 stage): patch rows 0 and TH + 1 lie outside the image: zeros, not multiplied.
+// STRIP (MODE & 4): see the head of the file; MODE 6 = STRIP on a map one tile high.
 template <int TH, int MODE>
 __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
-    constexpr bool MOSAIC = MODE == 1, ONE_ROW = MODE == 2;
-    constexpr int TW = TH, PH = TH + 2, NPIX = PH * PW, RH = TH / 2;
+    constexpr bool MOSAIC = (MODE & 3) == 1, ONE_ROW = (MODE & 3) == 2, STRIP = (MODE & 4) != 0;
+    static_assert(!(STRIP && MOSAIC), "one packing at a time");
+    constexpr int PW = STRIP ? 19 : 18;
+    constexpr int TW = STRIP ? 16 : TH, PH = TH + 2, NPIX = PH * PW, RH = TH / 2;
     constexpr int P_BLKS = (NPIX * 64 + 1023) / 1024, P_BYTES = P_BLKS * 1024, SLOT = KS * P_BYTES, NS = 2;
     constexpr int N_PIECES = KS * P_BLKS, MAX_P = (N_PIECES + NWT - 1) / NWT;
     constexpr int EX_BYTES = NWT * RH * 1024;                    // one KB per (wave, handed-over row)
@@ -82,6 +94,12 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
     };
     auto decode_tile = [&](int t, int &n, int &ty, int &tx) {
         if (MOSAIC) { n = t; ty = 0; tx = 0; return; }           // n = the mosaic; its images are 4n .. 4n + 3
+        if (STRIP) {                                            // n = image of lane 0, tx = its column there (lane l: strip column 16 ft + l)
+            const int ft = fastdiv(t, a.d_tx);
+            ty = t - ft * a.tiles_y;
+            n = fastdiv(ft * 16, a.d_tpi); tx = ft * 16 - n * a.W;
+            return;
+        }
         n = fastdiv(t, a.d_tpi);
         const int r = t - n * a.tiles_per_img;
         ty = fastdiv(r, a.d_tx); tx = r - ty * a.tiles_x;
@@ -99,7 +117,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         const int row = blk * 16 + (lane >> 2);
         int py = row / PW;
         const int px = row - py * PW;
-        if (row >= NPIX || px >= TW + 2 || j >= N_PIECES) py = 255;
+        if (row >= NPIX || px >= (STRIP ? PW : TW + 2) || j >= N_PIECES) py = 255;
         p_pk[k] = py | (px << 8) | (((((lane & 3) ^ swz64(row)) * 8) + hf * CK) << 16);
     }
     struct Cursor {
@@ -110,7 +128,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         int tile, n, ty, tx;
         decode_item(c.item, tile, c.cb);
         decode_tile(tile < a.n_tiles ? tile : 0, n, ty, tx);
-        c.n = tile < a.n_tiles ? n : -1; c.y0 = ty * TH - 1; c.x0 = tx * TW - 1;
+        c.n = tile < a.n_tiles ? n : -1; c.y0 = ty * TH - 1; c.x0 = (STRIP ? tx : tx * TW) - 1;
     };
     auto cursor_next = [&](Cursor &c) {
         if (++c.ck == a.n_steps_item) {
@@ -134,6 +152,11 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
                 const int img = c.n * 4 + (iy >> 3) * 2 + (ix >> 3), ly = iy & 7, lx = ix & 7;
                 in = c.n >= 0 && py != 255 && (unsigned)iy < 16u && (unsigned)ix < 16u && ly < 7 && lx < 7 && img < a.n_img && !(a.ablate & 2);
                 vo = in ? (unsigned)((((img * 7 + ly) * 7 + lx) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
+            } else if (STRIP) {                                 // position p holds image A's column x0 + p up to its right padding (column W), behind it image B from column 0
+                const bool second = ix > a.W;
+                const int img = c.n + (second ? 1 : 0), lx = second ? ix - a.W - 1 : ix;
+                in = c.n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)lx < (unsigned)a.W && img < a.n_img && !(a.ablate & 2);
+                vo = in ? (unsigned)((((img * a.H + iy) * a.W + lx) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
             } else {
                 in = c.n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && !(a.ablate & 2);
                 vo = in ? (unsigned)((((c.n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
@@ -158,11 +181,23 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
                      : "memory");
     };
 
+    // fragment addresses: lin = q' + frow (+ 1 for the STRIP lanes behind the tile's image boundary: the shared zero column lies between the images)
     int pbase[2][4];
+    auto set_pbase = [&](int fs) {
 #pragma unroll
-    for (int par = 0; par < 2; par++)
+        for (int par = 0; par < 2; par++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) pbase[par][c] = frow * 64 + ((fq ^ ((((frow + par) >> 1) + c) & 3)) << 4) + kg * P_BYTES;
+            for (int c = 0; c < 4; c++) pbase[par][c] = fs * 64 + ((fq ^ ((((fs + par) >> 1) + c) & 3)) << 4) + kg * P_BYTES;
+    };
+    set_pbase(frow);
+    auto strip_item = [&](int item_) {                          // STRIP: the lane shift of the item about to be multiplied
+        int tile, cb, n, ty, c0;
+        decode_item(item_, tile, cb);
+        decode_tile(tile < a.n_tiles ? tile : 0, n, ty, c0);
+        int fr = frow;
+        asm volatile("" : "+v"(fr));
+        set_pbase(fr + (fr >= a.W - c0 ? 1 : 0));
+    };
 
     f32x4 acc[TH];
     constexpr int PD = 4;                                       // pixel fragments read ahead
@@ -236,8 +271,12 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         const bool co_ok = co0 < a.Cout_p;
         // MOSAIC: wave group kg finishes mosaic row kg (RH = 8 tile rows = one image's 7 rows + the gutter); the lane's column picks the image
         if (MOSAIC) n = n * 4 + kg * 2 + (fr >> 3);
-        const int oy0 = MOSAIC ? 0 : ty * TH + kg * RH, ox = MOSAIC ? (fr & 7) : tx * TW + fr;
-        const bool t_ok = tile < a.n_tiles && co_ok && fr < TW && ox < a.W && (!MOSAIC || n < a.n_img);
+        const int c0 = tx;                                      // STRIP: lane 0's column in image n; lanes fr >= W - c0 are columns fr - (W - c0) of image n + 1
+        const bool sec = STRIP && fr >= a.W - c0;
+        const int n_tile = n;
+        if (STRIP) n += sec ? 1 : 0;
+        const int oy0 = MOSAIC ? 0 : ty * TH + kg * RH, ox = MOSAIC ? (fr & 7) : (STRIP ? c0 + fr - (sec ? a.W : 0) : tx * TW + fr);
+        const bool t_ok = tile < a.n_tiles && co_ok && fr < TW && ox < a.W && (!(MOSAIC || STRIP) || n < a.n_img);
         const unsigned rstride = (unsigned)(a.W * a.Cout_p * 2);
         const unsigned t_base = (unsigned)((((n * a.H + oy0) * a.W + ox) * a.Cout_p + co0) * 2);
         u32x2 rr[RH];
@@ -280,8 +319,10 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         asm volatile("" : "+v"(t2));
         const int q0 = t2 >> 3, c = t2 & 7;
         const int pr0 = q0 >> 4, pc = q0 & 15;
-        const int oxx = MOSAIC ? (pc & 7) : tx * TW + pc, co = cb * CBW + c * 8;
-        const bool okc = tile < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p;
+        const bool sec2 = STRIP && pc >= a.W - c0;
+        const int n2 = STRIP ? n_tile + (sec2 ? 1 : 0) : n;
+        const int oxx = MOSAIC ? (pc & 7) : (STRIP ? c0 + pc - (sec2 ? a.W : 0) : tx * TW + pc), co = cb * CBW + c * 8;
+        const bool okc = tile < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p && (!STRIP || n2 < a.n_img);
         const char *lsrc = stage + q0 * ROWB + (((c + pc) % CPX) << 4);
         if (MOSAIC) {       // rounds 0, 1: mosaic row 0 (image rows pr0, 4 + pr0), rounds 2, 3: mosaic row 1
             const int img0 = tile * 4 + (pc >> 3);
@@ -294,7 +335,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
             }
             return;
         }
-        const unsigned g0 = (unsigned)((((n * a.H + ty * TH + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
+        const unsigned g0 = (unsigned)((((n2 * a.H + ty * TH + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
 #pragma unroll
         for (int i = 0; i < ST_I; i++) {
             const int row = 4 * i + pr0;
@@ -361,6 +402,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         if (ck == 0) {
 #pragma unroll
             for (int r = 0; r < TH; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (STRIP) strip_item(item);
         }
         const int so = slot * SLOT;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_COL) : "memory");
@@ -395,6 +437,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
 
 template <int TH, int MODE = 0>
 static int ks_launch_t(fid_ctx *ctx, KSArgs &a, int per_wg) {
+    constexpr int PW = (MODE & 4) ? 19 : 18;
     constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     const int LDS = 2 * KS * P_BYTES + 1024 + NWT * (TH / 2) * 1024 + (a.ncls + 1) * CBW * 4;
     FID_REQUIRE(LDS <= 160 * 1024, "conv3x3_ks: %d bytes of LDS", LDS);
@@ -421,6 +464,22 @@ bool conv_ks_applicable(const ConvArgs &a) {
     return conv_wr_applicable(a);
 }
 
+// STRIP tiles (16 consecutive columns of the strip of all images' rows): every tile may cross at most ONE image boundary
+bool conv_strip_ok(const ConvArgs &a) {
+    if (getenv("FID_NO_STRIP") || a.W < 12) return false;
+    for (int k = 0, c0 = 0; k < a.W; k++, c0 = (c0 + 16) % a.W)
+        if (c0 + 15 >= 2 * a.W) return false;
+    return true;
+}
+// tile rows of a STRIP launch: the edge that pads the map's height least (ties: the taller tile re-fetches fewer halo rows)
+int conv_strip_rows(const ConvArgs &a) {
+    int best = 16;
+    for (int t : {14, 10})
+        if (cdiv(a.H, t) * t < cdiv(a.H, best) * best) best = t;
+    return best;
+}
+bool conv_ks_strip_applicable(const ConvArgs &a) { return conv_ks_applicable(a) && !conv_ks_mosaic(a) && conv_strip_ok(a); }
+
 static int ks_tile_rows(const ConvArgs &c) {
     if (conv_ks_mosaic(c)) return 16;
     auto padded = [&](int t) { return (long long)cdiv(c.H, t) * t * cdiv(c.W, t) * t; };
@@ -430,19 +489,19 @@ static int ks_tile_rows(const ConvArgs &c) {
     return t10 ? 10 : (t14 ? 14 : 16);
 }
 
-int conv_ks_items(const ConvArgs &c) {
-    const int TH = ks_tile_rows(c), B = c.M / (c.Ho * c.Wo);
-    const int tiles = conv_ks_mosaic(c) ? cdiv(B, 4) : B * cdiv(c.W, TH) * cdiv(c.H, TH);
+int conv_ks_items(const ConvArgs &c, bool strip) {
+    const int TH = strip ? conv_strip_rows(c) : ks_tile_rows(c), B = c.M / (c.Ho * c.Wo);
+    const int tiles = strip ? cdiv(B * c.W, 16) * cdiv(c.H, TH) : (conv_ks_mosaic(c) ? cdiv(B, 4) : B * cdiv(c.W, TH) * cdiv(c.H, TH));
     return tiles * cdiv(c.Cout_p, CBW);
 }
 
 // per_wg = 2: half the workgroups (at most half the CUs), two or more items each -- longer alone (IResNet-50 stage 3 at 64 faces: 27 vs 20 us per
 // layer) but on half the chip; with two batches in flight the other lane's kernels run on the free half.  The plan decides (tile 512 vs 256).
-int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c, int per_wg) {
+int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c, int per_wg, bool strip) {
     FID_REQUIRE(c.w_alt, "conv3x3_ks needs the fragment-order weights (repack kind 2)");
-    FID_REQUIRE(conv_ks_applicable(c), "conv3x3_ks: layer not applicable");
+    FID_REQUIRE(strip ? conv_ks_strip_applicable(c) : conv_ks_applicable(c), "conv3x3_ks: layer not applicable (strip %d)", (int)strip);
     const bool mosaic = conv_ks_mosaic(c);
-    const int TH = ks_tile_rows(c);
+    const int TH = strip ? conv_strip_rows(c) : ks_tile_rows(c);
     KSArgs a{};
     a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
@@ -452,11 +511,17 @@ int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c, int per_wg) {
     a.tiles_x = cdiv(c.W, TH);
     a.tiles_per_img = a.tiles_x * cdiv(c.H, TH);
     a.n_tiles = mosaic ? cdiv(B, 4) : B * a.tiles_per_img;
+    if (strip) {                                                // tile t = strip tile t / tiles_y, tile row t % tiles_y
+        a.tiles_y = cdiv(c.H, TH);
+        a.n_tiles = cdiv(B * c.W, 16) * a.tiles_y;
+        FID_REQUIRE((long long)B * c.W + 16 < (1ll << 27), "conv3x3_ks: strip of %d x %d columns", B, c.W);
+    }
     a.n_chunks = c.Cin_p / CK;
     a.n_steps_item = a.n_chunks / KS;
     a.n_cblk = cdiv(c.Cout_p, CBW);
     a.n_items = a.n_tiles * a.n_cblk;
     a.d_cblk = fastdiv_make(a.n_cblk); a.d_tpi = fastdiv_make(a.tiles_per_img); a.d_tx = fastdiv_make(a.tiles_x);
+    if (strip) { a.d_tpi = fastdiv_make(c.W); a.d_tx = fastdiv_make(a.tiles_y); }
     a.in_bytes = c.in_bytes;
     const size_t ob = (size_t)c.M * c.Cout_p * 2;
     FID_REQUIRE(a.in_bytes <= OOB && ob <= OOB, "conv: tensor larger than 2 GiB");
@@ -465,6 +530,11 @@ int conv_ks_launch(fid_ctx *ctx, const ConvArgs &c, int per_wg) {
     a.ncls = c.bias ? ((c.flags & CF_BORDER) ? 9 : 1) : 0;
     static const int ablate = getenv("FID_KS_ABLATE") ? atoi(getenv("FID_KS_ABLATE")) : 0;
     a.ablate = ablate;
+    if (strip) {
+        if (TH == 10) return ks_launch_t<10, 4>(ctx, a, per_wg);
+        if (TH == 14) return c.H == 14 ? ks_launch_t<14, 6>(ctx, a, per_wg) : ks_launch_t<14, 4>(ctx, a, per_wg);
+        return ks_launch_t<16, 4>(ctx, a, per_wg);
+    }
     if (mosaic) return ks_launch_t<16, 1>(ctx, a, per_wg);
     if (TH == 10) return ks_launch_t<10>(ctx, a, per_wg);
     if (TH == 14) return c.H == 14 ? ks_launch_t<14, 2>(ctx, a, per_wg) : ks_launch_t<14>(ctx, a, per_wg);

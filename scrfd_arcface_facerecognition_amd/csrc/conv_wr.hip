@@ -37,7 +37,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB = 0x7FFFFFF0u;
-constexpr int PW = 18, CK = 32;                                   // patch width, channels per step
+constexpr int CK = 32;                                            // channels per step (patch width: 18 positions, 19 with STRIP tiles)
 
 __device__ __forceinline__ int swz64(int lin) { return (lin >> 1) & 3; }
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -59,6 +59,7 @@ struct WRArgs {
     FastDiv d_cblk, d_tpi, d_tx;
     unsigned in_bytes, out_bytes, w_bytes;
     int tab_off, ncls;   // LDS offset of the bias [ncls][Cout_p] + slope [Cout_p] fp32 tables; ncls = 9 with CF_BORDER else 1 (0: no bias)
+    int n_img, tiles_y;  // STRIP: images of the strip, tile rows; tile t = (strip tile t / tiles_y, tile row t % tiles_y), d_tx divides by tiles_y, d_tpi by W
     int rev;      // walk the items from the last to the first (see ConvArgs::rev)
     int stagger;  // experiment: workgroups in the second half of the grid (the co-resident ones) start this many x 64 cycles late
     int ablate;   // FID_WR_ABLATE timing experiments (wrong results): 1 no step barrier, 2 no patch pieces, 4 no weight reloads, 8 no epilogue, 32 stores dropped, 64 no residual loads
@@ -70,10 +71,17 @@ struct WRArgs {
 //              in registers for the kernel's lifetime: only patches are fetched (SCRFD's 64 / 96-channel stacks at 160x160 / 80x80)
 // NS: patch slots -- pieces are requested NS - 1 steps ahead (4: the one-tile variant on small batches, where a step is ~1 us, shorter
 //     than a trip to memory, and there is no second workgroup on the CU to hide it)
-template <int TH, int NT, int NW, int NCH, int NS = 2>
+// STRIP (round 5): x-packed pixel fragments -- a tile is TH rows x 16 consecutive columns of the strip formed by the rows of all images side by
+//     side (conv_ks.hip describes the addressing): no idle lanes on 14 / 28 / 56 / 112 / 20 / 40-wide maps
+// XF: bit 0 = STRIP, bit 1 = ONE_ROW (the map is one tile high, H = TH: patch rows 0 and TH + 1 lie outside the image -- zeros, neither read nor multiplied:
+//     120 of 126 products per tile and step on IResNet's 14x14 stage, as conv3x3_ks<14, 2> does)
+template <int TH, int NT, int NW, int NCH, int NS = 2, int XF = 0>
 __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
+    constexpr bool STRIP = (XF & 1) != 0, ONE_ROW = (XF & 2) != 0;
+    static_assert(!ONE_ROW || NCH == 0, "ONE_ROW: streaming variants only (the deferred write-out is scheduled on the full row list)");
     constexpr int CBW = NW * 16;                                // couts per item
-    constexpr int TW = TH;                                      // tile stride in x (16 lanes per fragment; lanes >= TW are not stored)
+    constexpr int PW = STRIP ? 19 : 18;                         // patch positions per row (STRIP: one shared zero column between the tile's two images)
+    constexpr int TW = STRIP ? 16 : TH;                         // tile stride in x (16 lanes per fragment; lanes >= TW are not stored)
     constexpr int PH = TH + 2, NPIX = PH * PW;
     constexpr int P_BLKS = (NPIX * 64 + 1023) / 1024, P_BYTES = P_BLKS * 1024, SLOT = NT * P_BYTES;
     constexpr int MAX_P = (NT * P_BLKS + NW - 1) / NW;          // patch pieces per wave and step
@@ -92,9 +100,20 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         cb = item - pair * a.n_cblk;
     };
     auto decode_tile = [&](int t, int &n, int &ty, int &tx) {
+        if (STRIP) {                                            // n = image of lane 0, tx = its column there (lane l: strip column 16 ft + l)
+            const int ft = fastdiv(t, a.d_tx);
+            ty = t - ft * a.tiles_y;
+            n = fastdiv(ft * 16, a.d_tpi); tx = ft * 16 - n * a.W;
+            return;
+        }
         n = fastdiv(t, a.d_tpi);
         const int r = t - n * a.tiles_per_img;
         ty = fastdiv(r, a.d_tx); tx = r - ty * a.tiles_x;
+    };
+    // STRIP: lane / tile column l of a tile whose lane 0 is column c0 of image n -> its image and column
+    auto strip_px = [&](int n, int c0, int l, int &img, int &x) {
+        const bool sec = l >= a.W - c0;
+        img = n + (sec ? 1 : 0); x = c0 + l - (sec ? a.W : 0);
     };
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, a.in_bytes, 0x00020000);
     const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, a.out_bytes, 0x00020000);
@@ -109,7 +128,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         const int row = blk * 16 + (lane >> 2);
         int py = row / PW;
         const int px = row - py * PW;
-        if (row >= NPIX || px >= TW + 2 || j >= NT * P_BLKS) py = 255;
+        if (row >= NPIX || px >= (STRIP ? PW : TW + 2) || j >= NT * P_BLKS) py = 255;
         p_pk[k] = py | (px << 8) | ((((lane & 3) ^ swz64(row)) * 8) << 16) | (h << 24);
     }
     struct Cursor {
@@ -124,7 +143,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             const int t = pair * NT + h;
             int n, ty, tx;
             decode_tile(t < a.n_tiles ? t : 0, n, ty, tx);
-            c.n[h] = t < a.n_tiles ? n : -1; c.y0[h] = ty * TH - 1; c.x0[h] = tx * TW - 1;
+            c.n[h] = t < a.n_tiles ? n : -1; c.y0[h] = ty * TH - 1; c.x0[h] = (STRIP ? tx : tx * TW) - 1;
         }
     };
     auto cursor_next = [&](Cursor &c) {
@@ -144,9 +163,16 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
             const int h = pk >> 24, py = pk & 255;
             const int n = h ? c.n[NT - 1] : c.n[0], y0 = h ? c.y0[NT - 1] : c.y0[0], x0 = h ? c.x0[NT - 1] : c.x0[0];
-            const int iy = y0 + py, ix = x0 + ((pk >> 8) & 255);
-            const bool in = n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned vo = in ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin_p + c0 + ((pk >> 16) & 255)) * 2) : OOB;
+            const int iy = y0 + py;
+            int ix = x0 + ((pk >> 8) & 255), img = n;
+            bool in = n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H;
+            if (STRIP) {                                        // position p holds image A's column x0 + p up to its right padding (column W), behind it image B from column 0
+                const bool second = ix > a.W;
+                img += second ? 1 : 0; ix = second ? ix - a.W - 1 : ix;
+                in = in && img < a.n_img;
+            }
+            in = in && (unsigned)ix < (unsigned)a.W;
+            const unsigned vo = in ? (unsigned)((((img * a.H + iy) * a.W + ix) * a.Cin_p + c0 + ((pk >> 16) & 255)) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, vo, 0, 0, 0);
         }
     };
@@ -169,11 +195,32 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
 
     // ---- pixel fragment addresses: lin = q' + frow with q' a compile-time constant; the swizzled 16-byte group is one of four
     // per lane, selected by the parity of q' and (q' >> 1) & 3 -- precomputed, so a fragment read is one ds_read with an immediate
-    int pbase[2][4];
+    // STRIP: lanes behind the tile's image boundary read one position further right (the shared zero column lies between the images): per tile of the item
+    // (the 16-row pair variant has no registers for a second set: the host gives it pairs of tiles with one boundary position -- an even number of
+    // tile rows, so that a pair is two rows of one strip tile, or a width that is a multiple of 16)
+    constexpr int NPB = (STRIP && !(TH == 16 && NT == 2)) ? NT : 1;
+    int pbase[NPB][2][4];
+    auto set_pbase = [&](int t, int fs) {
 #pragma unroll
-    for (int par = 0; par < 2; par++)
+        for (int par = 0; par < 2; par++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) pbase[par][c] = frow * 64 + ((fq ^ ((((frow + par) >> 1) + c) & 3)) << 4);
+            for (int c = 0; c < 4; c++) pbase[t][par][c] = fs * 64 + ((fq ^ ((((fs + par) >> 1) + c) & 3)) << 4);
+    };
+#pragma unroll
+    for (int t = 0; t < NPB; t++) set_pbase(t, frow);
+    auto strip_item = [&](int item_) {                          // STRIP: the lane shifts of the item about to be multiplied
+        int pair, cb;
+        decode_item(item_, pair, cb);
+        int fr = frow;
+        asm volatile("" : "+v"(fr));
+#pragma unroll
+        for (int t = 0; t < NPB; t++) {
+            const int tile = pair * NT + t;
+            int n, ty, c0;
+            decode_tile(tile < a.n_tiles ? tile : 0, n, ty, c0);
+            set_pbase(t, fr + (fr >= a.W - c0 ? 1 : 0));
+        }
+    };
 
     f32x4 acc[NT][TH];
 
@@ -186,15 +233,17 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
         constexpr int WB = decltype(wb_tag)::value * 9;
         // the eight per-lane fragment bases of this slot, made opaque: every read is then "base register + immediate" -- left to
         // itself the compiler hoists one address register PER READ out of the step loop (54 VGPRs of loop-invariant addresses)
-        int pb[2][4];
+        int pb[NPB][2][4];
         const int slot_off = (int)(sP - smem);
+#pragma unroll
+        for (int t = 0; t < NPB; t++)
 #pragma unroll
         for (int par = 0; par < 2; par++)
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                pb[par][c] = pbase[par][c] + slot_off;
+                pb[t][par][c] = pbase[t][par][c] + slot_off;
 #ifndef WR_NO_PB
-                asm volatile("" : "+v"(pb[par][c]));
+                asm volatile("" : "+v"(pb[t][par][c]));
 #endif
             }
         half8 pq[PD + 1][NT];
@@ -202,17 +251,19 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             const int K = (q % PH) * PW + q / PH;               // lin = K + frow
 #pragma unroll
             for (int t = 0; t < NT; t++)
-                pq[set][t] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + (K * 64 + t * P_BYTES)));
+                pq[set][t] = *(const half8 *)(smem + (pb[NPB > 1 ? t : 0][K & 1][(K >> 1) & 3] + (K * 64 + t * P_BYTES)));
         };
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) {
             if (dx != dx_) continue;
+            constexpr int NR = ONE_ROW ? TH : PH, R0 = ONE_ROW ? 1 : 0;     // patch rows read: R0 .. R0 + NR - 1
 #pragma unroll
-            for (int r = 0; r < PD; r++) load_p(dx * PH + r, r % (PD + 1));
+            for (int j = 0; j < PD; j++) load_p(dx * PH + R0 + j, j % (PD + 1));
 #pragma unroll
-            for (int r = 0; r < PH; r++) {
+            for (int j = 0; j < NR; j++) {
+                const int r = R0 + j;
                 const int q = dx * PH + r;
-                if (r + PD < PH) load_p(q + PD, (r + PD) % (PD + 1));
+                if (j + PD < NR) load_p(q + PD, (j + PD) % (PD + 1));
                 row_hook(dx, r);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -220,7 +271,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
                     const int mi = r - dy;
                     if (mi < 0 || mi >= TH) continue;
 #pragma unroll
-                    for (int t = 0; t < NT; t++) acc[t][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[WB + dy * 3 + dx], pq[r % (PD + 1)][t], acc[t][mi], 0, 0, 0);
+                    for (int t = 0; t < NT; t++) acc[t][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[WB + dy * 3 + dx], pq[j % (PD + 1)][t], acc[t][mi], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -290,9 +341,11 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             const int pl = off / ROWB, pos = (off - pl * ROWB) >> 4;
             const int pr = pl >> 4, pc = pl & 15;
             const int c = (pos + CPX - pc % CPX) % CPX;         // the staged layout rotates a pixel's chunks by its column
-            const int oy = ty * TH + pr, ox = tx * TW + pc;
-            const bool ok = j < RS_BLKS && pl < TH * 16 && pair < a.n_tiles && pc < TW && oy < a.H && ox < a.W && c * 8 < a.Cout_p;
-            const unsigned vo = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.Cout_p + c * 8) * 2) : OOB;
+            int nn = n, ox = tx * TW + pc;
+            if (STRIP) strip_px(n, tx, pc, nn, ox);
+            const int oy = ty * TH + pr;
+            const bool ok = j < RS_BLKS && pl < TH * 16 && pair < a.n_tiles && pc < TW && oy < a.H && ox < a.W && c * 8 < a.Cout_p && (!STRIP || nn < a.n_img);
+            const unsigned vo = ok ? (unsigned)((((nn * a.H + oy) * a.W + ox) * a.Cout_p + c * 8) * 2) : OOB;
             char *dst = j < RS_BLKS ? sR + j * 1024 : smem + NS * SLOT;     // surplus piece: the spare KB
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, (__attribute__((address_space(3))) void *)dst, 16, vo, 0, 0, 0);
         }
@@ -333,8 +386,10 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             int n, ty, tx;
             decode_tile(tile < a.n_tiles ? tile : 0, n, ty, tx);
             t_oy0[t] = ty * TH;
-            t_ok[t] = tile < a.n_tiles && co_ok && fr < TW && tx * TW + fr < a.W;
-            t_base[t] = (unsigned)((((n * a.H + ty * TH) * a.W + tx * TW + fr) * a.Cout_p + co0) * 2);
+            int nn = n, oxl = tx * TW + fr;
+            if (STRIP) strip_px(n, tx, fr, nn, oxl);
+            t_ok[t] = tile < a.n_tiles && co_ok && fr < TW && oxl < a.W && (!STRIP || nn < a.n_img);
+            t_base[t] = (unsigned)((((nn * a.H + ty * TH) * a.W + oxl) * a.Cout_p + co0) * 2);
         }
         u32x2 rrA[RG], rrB[RG];
         auto load_group = [&](int gi, u32x2 (&rr)[RG]) {        // gi -> (tile, pass, group in pass); exactly RG loads
@@ -349,7 +404,9 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             const int tile = pair * NT + t;
             int n, ty, tx;
             decode_tile(tile < a.n_tiles ? tile : 0, n, ty, tx);
-            const int oy0 = ty * TH, ox0 = tx * TW, ox = ox0 + fr;
+            const int oy0 = ty * TH, ox0 = tx * TW;
+            int ox = ox0 + fr, n_l = n;
+            if (STRIP) strip_px(n, tx, fr, n_l, ox);
             f32x4 btop = bmid, bbot = bmid;
             if (BORDER) {       // exact fold of a BatchNorm in front of the zero-padded conv: the bias row depends on the pixel's border class
                 const int xc = ox == 0 ? 0 : (ox == a.W - 1 ? 2 : 1);
@@ -401,10 +458,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
                 asm volatile("" : "+v"(lo2));                   // opaque again: the constants are recomputed per pass, not kept in registers
                 const int wl = wave * 64 + lo2, q0 = wl / CPX, c = wl - q0 * CPX;
                 const int pr0 = q0 >> 4, pc = q0 & 15;          // row / column of the lane's first pixel inside the pass
-                const int oxx = ox0 + pc, co = cb * CBW + c * 8;
-                const bool okc = tile < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p;
+                int oxx = ox0 + pc, n2 = n;
+                if (STRIP) strip_px(n, tx, pc, n2, oxx);
+                const int co = cb * CBW + c * 8;
+                const bool okc = tile < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p && (!STRIP || n2 < a.n_img);
                 const char *lsrc = stage + q0 * ROWB + (((c + pc) % CPX) << 4);
-                const unsigned g0 = (unsigned)((((n * a.H + oy0 + r0 + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
+                const unsigned g0 = (unsigned)((((n2 * a.H + oy0 + r0 + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
                 const int rows_left = (a.H - oy0 < TH ? a.H - oy0 : TH) - r0 - pr0;     // rows of the pass this lane may store: 2 i < rows_left
 #pragma unroll
                 for (int i = 0; i < ST_I; i++) {
@@ -472,10 +531,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             decode_tile(ptile >= 0 && ptile < a.n_tiles ? ptile : 0, n, ty, tx);
             const int wl = wave * 64 + lo2, q0 = wl / CPX, c = wl - q0 * CPX;
             const int pr0 = q0 >> 4, pc = q0 & 15;
-            const int oy0 = ty * TH, oxx = tx * TW + pc, co = c * 8;
-            const bool okc = ptile >= 0 && ptile < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p && !(a.ablate & 32);
+            int oxx = tx * TW + pc, n2 = n;
+            if (STRIP) strip_px(n, tx, pc, n2, oxx);
+            const int oy0 = ty * TH, co = c * 8;
+            const bool okc = ptile >= 0 && ptile < a.n_tiles && pc < TW && oxx < a.W && co < a.Cout_p && !(a.ablate & 32) && (!STRIP || n2 < a.n_img);
             wo_src = sR + q0 * ROWB + (((c + pc) % CPX) << 4);
-            wo_g0 = (unsigned)((((n * a.H + oy0 + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
+            wo_g0 = (unsigned)((((n2 * a.H + oy0 + pr0) * a.W + oxx) * a.Cout_p + co) * 2);
             wo_rows = okc ? (a.H - oy0 < TH ? a.H - oy0 : TH) - pr0 : 0;      // 2 i < wo_rows: the lane may store row 2 i + pr0 of the tile
             wo_pr0 = pr0;
         };
@@ -516,6 +577,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             if (C == 0) {
 #pragma unroll
                 for (int r = 0; r < TH; r++) acc[0][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (STRIP) strip_item(item);
             }
             const char *sP = smem + (s & 1) * SLOT;
             if constexpr (DEFER && C == 0) {
@@ -609,6 +671,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int r = 0; r < TH; r++) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (STRIP) strip_item(item);
         }
         const char *sP = smem + slot * SLOT;
         WR_WAIT_E(N_COL, e_col, asm volatile("" : "+v"(w[0]), "+v"(w[3]), "+v"(w[6])));
@@ -649,8 +712,9 @@ bool conv_wr_applicable(const ConvArgs &a) {
            (a.res == nullptr || (a.res_H == a.Ho && a.res_W == a.Wo && a.res_Cp == a.Cout_p));
 }
 
-template <int TH, int NT, int NW, int NCH, int NS = 2>
+template <int TH, int NT, int NW, int NCH, int NS = 2, int XF = 0>
 static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
+    constexpr int PW = (XF & 1) ? 19 : 18;
     constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     constexpr int RS_BYTES = NCH > 0 ? ((TH * 16 * NW * 32 + 1023) / 1024) * 1024 : 0;      // resident variant: the residual tile
     a.ncls = a.bias ? ((a.flags & CF_BORDER) ? 9 : 1) : 0;
@@ -661,12 +725,12 @@ static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
     a.n_items = cdiv(n_tiles, NT) * a.n_cblk;
     a.d_cblk = fastdiv_make(a.n_cblk);
     FID_REQUIRE(NCH == 0 || (a.n_chunks == NCH && a.n_cblk == 1), "conv3x3_wr: resident variant %d x %d on %d chunks / %d cout blocks", NW * 16, NCH, a.n_chunks, a.n_cblk);
-    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_wr<TH, NT, NW, NCH, NS>, (int)(LDS)));
+    FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_wr<TH, NT, NW, NCH, NS, XF>, (int)(LDS)));
     // waves per CU by registers: > 168 VGPRs -> two per SIMD (8 per CU); the one-tile streaming variant stays below 168 -> three per SIMD
     const int wg_per_cu = std::max(1, std::min((NT == 1 && NCH == 0 && TH <= 14 ? 12 : 8) / NW, (160 * 1024) / LDS));
     static const int wgpc_env = getenv("FID_WR_WGPC") ? atoi(getenv("FID_WR_WGPC")) : 0;
     const int grid = std::min(a.n_items, ctx->num_cus * (wgpc_env > 0 ? wgpc_env : wg_per_cu));
-    hipLaunchKernelGGL((conv3x3_wr<TH, NT, NW, NCH, NS>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
+    hipLaunchKernelGGL((conv3x3_wr<TH, NT, NW, NCH, NS, XF>), dim3(grid), dim3(NW * 64), LDS, ctx->stream, a);
     FID_HIP(hipGetLastError());
     return FID_OK;
 }
@@ -680,8 +744,9 @@ bool conv_wr_resident_ok(const ConvArgs &a) {
 
 // nt x cb: 2 x 128 (large batches: a pair of tiles x 128 couts on 8 waves) | 1 x 64 (four waves, two workgroups per CU: enough items
 // for every CU when there are only a few hundred tiles); resident: one tile x all couts with the layer's weights kept in registers
-int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident, int ring) {
+int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident, int ring, bool strip) {
     FID_REQUIRE(c.w_alt, "conv3x3_wr needs the fragment-order weights (repack kind 2)");
+    FID_REQUIRE(!strip || (conv_strip_ok(c) && ring != 4), "conv3x3_wr: no STRIP tiling for a %d-wide map (ring %d)", c.W, ring);
     FID_REQUIRE(resident ? conv_wr_resident_ok(c) : ((nt == 2 && cb == 128) || (nt == 1 && cb == 64)), "conv3x3_wr: no %d x %d variant (resident %d)", nt, cb, resident);
     // tile edge 14 or 16: whichever computes fewer pixels for this map (14 fits IResNet's 112 / 56 / 28 / 14 maps exactly and a 40x40
     // map in 3x3 tiles of 196 = 91 % useful pixels, where 16x16 tiles compute 48x48 for 69 %)
@@ -691,7 +756,12 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
     // instantiated for the one-tile variants those small maps take (resident, and streaming x 64 couts)
     auto work = [&](int t) { return (double)padded(t) * 16.0 / t; };      // matrix rows x 16 lanes the tiling computes
     const bool t10 = (resident || (nt == 1 && ring != 4)) && work(10) < 0.9 * std::min(work(14), work(16));
-    const int TH = t10 ? 10 : (t14 ? 14 : 16);
+    int TH = t10 ? 10 : (t14 ? 14 : 16);
+    if (strip) {                                              // rows only: the strip has no padded columns (10-row tiles exist for the one-tile variants)
+        TH = conv_strip_rows(c);
+        if (TH == 10 && !(resident || nt == 1)) TH = cdiv(c.H, 14) * 14 <= cdiv(c.H, 16) * 16 ? 14 : 16;
+        if (TH == 16 && nt == 2 && c.W % 16 != 0 && cdiv(c.H, 16) % 2 != 0) TH = 14;      // (the 16-row pair kernel keeps ONE set of lane shifts per item)
+    }
     WRArgs a{};
     a.in = c.in; a.w = c.w_alt; a.bias = c.bias; a.slope = c.slope; a.res = c.res; a.out = c.out;
     a.H = c.H; a.W = c.W; a.Cin_p = c.Cin_p; a.Cout_p = c.Cout_p;
@@ -706,6 +776,13 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
     a.n_tiles = B * a.tiles_per_img;
     a.n_chunks = c.Cin_p / CK;
     a.d_tpi = fastdiv_make(a.tiles_per_img); a.d_tx = fastdiv_make(a.tiles_x);
+    a.n_img = B;
+    if (strip) {                                              // tile t = strip tile t / tiles_y, tile row t % tiles_y
+        a.tiles_y = cdiv(c.H, TH);
+        a.n_tiles = cdiv(B * c.W, 16) * a.tiles_y;
+        a.d_tpi = fastdiv_make(c.W); a.d_tx = fastdiv_make(a.tiles_y);
+        FID_REQUIRE((long long)B * c.W + 16 < (1ll << 27), "conv3x3_wr: strip of %d x %d columns", B, c.W);
+    }
     a.in_bytes = c.in_bytes;
     const size_t ob = (size_t)c.M * c.Cout_p * 2;
     FID_REQUIRE(a.in_bytes <= OOB && ob <= OOB, "conv: tensor larger than 2 GiB");
@@ -713,7 +790,8 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
     a.w_bytes = (unsigned)repack_bytes(2, c.Cout_p, c.Cin_p);
     if (resident) {
         const int key = (c.Cout_p / 16) * 10 + a.n_chunks;
-#define WR_RES(NWV, NCHV) (t10 ? wr_launch_t<10, 1, NWV, NCHV>(ctx, a, a.n_tiles) : t14 ? wr_launch_t<14, 1, NWV, NCHV>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, NWV, NCHV>(ctx, a, a.n_tiles))
+#define WR_RES(NWV, NCHV) (strip ? (TH == 10 ? wr_launch_t<10, 1, NWV, NCHV, 2, 1>(ctx, a, a.n_tiles) : TH == 14 ? wr_launch_t<14, 1, NWV, NCHV, 2, 1>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, NWV, NCHV, 2, 1>(ctx, a, a.n_tiles)) \
+                                : (t10 ? wr_launch_t<10, 1, NWV, NCHV>(ctx, a, a.n_tiles) : t14 ? wr_launch_t<14, 1, NWV, NCHV>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, NWV, NCHV>(ctx, a, a.n_tiles)))
         switch (key) {
             case 42: return WR_RES(4, 2);
             case 43: return WR_RES(4, 3);
@@ -724,6 +802,12 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
 #undef WR_RES
         set_error("conv3x3_wr: no resident variant for %d couts x %d chunks", c.Cout_p, a.n_chunks);
         return FID_E_INVALID;
+    }
+    if (strip) {
+        const bool one = c.H == 14 && TH == 14;                // the map is one tile high: the two halo rows are skipped
+        if (nt == 2) return TH == 14 ? (one ? wr_launch_t<14, 2, 8, 0, 2, 3>(ctx, a, a.n_tiles) : wr_launch_t<14, 2, 8, 0, 2, 1>(ctx, a, a.n_tiles)) : wr_launch_t<16, 2, 8, 0, 2, 1>(ctx, a, a.n_tiles);
+        if (TH == 10) return wr_launch_t<10, 1, 4, 0, 2, 1>(ctx, a, a.n_tiles);
+        return TH == 14 ? (one ? wr_launch_t<14, 1, 4, 0, 2, 3>(ctx, a, a.n_tiles) : wr_launch_t<14, 1, 4, 0, 2, 1>(ctx, a, a.n_tiles)) : wr_launch_t<16, 1, 4, 0, 2, 1>(ctx, a, a.n_tiles);
     }
     if (nt == 2) return t14 ? wr_launch_t<14, 2, 8, 0>(ctx, a, a.n_tiles) : wr_launch_t<16, 2, 8, 0>(ctx, a, a.n_tiles);
     if (ring == 4) return t14 ? wr_launch_t<14, 1, 4, 0, 4>(ctx, a, a.n_tiles) : wr_launch_t<16, 1, 4, 0, 4>(ctx, a, a.n_tiles);

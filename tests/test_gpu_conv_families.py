@@ -35,6 +35,12 @@ def forced_ran(cn, code):
             return p["gen"] == 9 and p["ns"] == 4
         if code in (96, 97):                                    # conv_ks: one / two items per workgroup (plan tile 256 / 512)
             return p["gen"] == 9 and p["ns"] == 6 and p["bm"] == (256 if code == 96 else 512)
+        if code == 98:                                          # conv_ks on x-packed STRIP tiles
+            return p["gen"] == 9 and p["ns"] == 7
+        if code in (909, 929):                                  # conv_wr on STRIP tiles: one tile x 64 couts / a pair x 128 couts
+            return p["gen"] == 9 and p["ns"] == 8 and p["bm"] == (256 if code == 909 else 512)
+        if code == 910:                                         # conv_wr on STRIP tiles, the layer's weights resident
+            return p["gen"] == 9 and p["ns"] == 9
         return p["gen"] == code
     return [p["name"] for p in cn.plans() if hit(p)]
 
@@ -57,7 +63,10 @@ def stack(hw, chans, res=True):
 # a pair of tiles x 128 couts per item / (93) one tile x all couts with the layer's weights resident in registers (64 / 96 / 128-cout layers of 64 / 96 channels) / (94) one tile x 64 couts with a four-slot patch ring (pieces three steps ahead); 11 = implicit GEMM with the weights in registers (conv_gw: every conv with >= 96 couts, any kernel size / stride)
 # 96 = generation 9 with the K axis split over two wave groups (conv_ks.hip: one tile x 64 couts per item, 8 waves; layers with an even number of 32-channel chunks);
 # 97 = the same with two items per workgroup (offered when there are no more items than CUs: half the workgroups, the persistent item loop)
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 91, 92, 93, 94, 96, 97, 11, 25, 51, 59])
+# 98 = conv_ks on x-packed STRIP tiles (round 5): a tile is 16 consecutive columns of the strip of all images' rows (the (14, 14) x 5 case: 70 strip
+#      columns = four full tiles and one of six lanes; (37, 21): every one of 21 boundary positions inside a tile)
+# 909 / 929 / 910 = conv_wr on STRIP tiles (one tile x 64 couts / a pair of tiles x 128 couts / the resident-weight variant)
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 91, 92, 93, 94, 96, 97, 98, 909, 929, 910, 11, 25, 51, 59])
 @pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2), ((37, 21), (64, 64), 3),
                                             ((14, 14), (128, 128), 5), ((20, 20), (64, 96), 4), ((20, 20), (224, 224), 3)])
 def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
@@ -65,7 +74,10 @@ def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
     if gen == 59:
         monkeypatch.setenv("FID_FORCE_GEN", "5")
         monkeypatch.setenv("FID_PC_RS", "1")
-    elif gen in (25, 51, 91, 92, 93, 94, 96, 97):
+    elif gen >= 900:
+        monkeypatch.setenv("FID_FORCE_GEN", str(gen // 100))
+        monkeypatch.setenv("FID_FORCE_NS", str(gen % 100))
+    elif gen in (25, 51, 91, 92, 93, 94, 96, 97, 98):
         monkeypatch.setenv("FID_FORCE_GEN", str(gen // 10))
         monkeypatch.setenv("FID_FORCE_NS", str(gen % 10))
     else:
@@ -108,6 +120,38 @@ def test_conv_mosaic_7x7(ctx, monkeypatch, gen, chans, batch):
         assert len(ran) >= (3 if gen == 96 else 1), ran                 # every 3x3 conv of the stack but the 3-channel one (and a1 after 64 -> 192: still even chunk counts)
     elif not ran:
         pytest.skip("conv_gw takes no layer of this stack")
+    ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))[net.outputs[0]]
+    ref = np.transpose(ref, (0, 2, 3, 1))
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3, ran
+
+
+# STRIP tiles (round 5): x-packed pixel fragments -- image counts that fill / do not fill the last tile, a single image, maps of one / two / three
+# tile rows, every lane position of the image boundary (21-wide rows), plain / border-class bias, PReLU, residual; against the oracle
+@pytest.mark.parametrize("gen", [98, 909, 929, 910])
+@pytest.mark.parametrize("hw,chans,batch", [((14, 14), (128, 128), 8), ((14, 14), (64, 256), 9), ((14, 14), (128, 64), 1), ((14, 14), (64, 128), 17),
+                                            ((28, 28), (128, 128), 3), ((20, 20), (64, 192), 5), ((12, 12), (64, 64), 6), ((15, 15), (128, 64), 4),
+                                            ((37, 21), (64, 128), 3), ((40, 40), (64, 64), 2), ((56, 56), (64, 128), 3), ((40, 40), (96, 96), 3),
+                                            ((20, 20), (96, 64), 5), ((20, 20), (224, 224), 3)])
+def test_conv_strip(ctx, monkeypatch, gen, hw, chans, batch):
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet
+    monkeypatch.setenv("FID_FORCE_GEN", str(gen // (100 if gen >= 900 else 10)))
+    monkeypatch.setenv("FID_FORCE_NS", str(gen % (100 if gen >= 900 else 10)))
+    net = stack(hw, chans)
+    P = archs.synth_params(net, seed=41)
+    images = np.random.default_rng(43).integers(0, 256, (batch,) + hw + (3,), dtype=np.uint8)
+    cn = CompiledNet(ctx, net, P, max_batch=batch)
+    cn.run(images)
+    got = cn.read(net.outputs[0], batch)
+    ran = forced_ran(cn, gen)
+    cn.close()
+    if gen == 910:                                         # resident weights: 64 / 96-channel layers with at most 128 couts
+        if not ran:
+            pytest.skip("no layer of this stack keeps its weights resident")
+    elif gen == 98 and any(c % 64 for c in chans):
+        if not ran:
+            pytest.skip("conv_ks needs an even number of 32-channel chunks")
+    else:
+        assert len(ran) >= 2, ran                          # at least the convs on the second channel count
     ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))[net.outputs[0]]
     ref = np.transpose(ref, (0, 2, 3, 1))
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3, ran

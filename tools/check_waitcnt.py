@@ -7,7 +7,8 @@ hoisting one across it -- silent wrong data, not a fault.  This script disassemb
 (llvm-objdump), reduces every kernel to its stream of vector-memory events
 
     W<n>  s_waitcnt vmcnt(n)        L<k>  k loads to registers        D<k>  k loads to LDS (`... lds`)
-    S<k>  k stores                  B     s_barrier                   |     a branch (the next run may be the other arm)
+    S<k>  k stores                  B     s_barrier                   |     a branch (the next run may be the other arm; forward
+                                                                            skips over plain ALU code leave no token)
 
 and compares the part between the first and the last counted (n > 0) wait with the signature recorded for that kernel in
 csrc/waitcnt.sig (one line per kernel: name <TAB> signature).  A signature is the declared count table of the kernel: the per-step
@@ -54,18 +55,35 @@ def demangle(names):
 
 
 def kernel_streams(text):
-    """{mangled kernel name: token list}"""
-    kernels, cur = {}, None
+    """{mangled kernel name: token list}.  A FORWARD branch whose skipped range holds no vector-memory operation, barrier or wait (the
+    compiler wraps per-lane address arithmetic in `s_cbranch_execz` skips) is not a fork of the event stream and leaves no token:
+    every path through it issues the same operations.  Backward branches (loops) and forward branches over events stay
+    as `|`: the runs on both sides of such a token are alternative arms and must be compared arm by arm when a signature is reviewed."""
+    kernels, cur, base = {}, None, 0
+    pending = []                                   # (index in cur of a forward-branch token, target address)
     for line in text.splitlines():
-        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        m = re.match(r"^([0-9a-f]+) <([^>]+)>:", line)
         if m:
-            cur = kernels.setdefault(m.group(1), [])
+            cur = kernels.setdefault(m.group(2), [])
+            base = int(m.group(1), 16)
+            pending = []
             continue
         if cur is None:
             continue
-        ins = line.strip().split("//")[0].strip()
+        parts = line.strip().split("//")
+        ins = parts[0].strip()
         if not ins:
             continue
+        addr = None
+        if len(parts) > 1:
+            ma = re.match(r"\s*([0-9A-Fa-f]+):", parts[1])
+            if ma:
+                addr = int(ma.group(1), 16)
+        if addr is not None:                       # forward branches that land here: drop the ones that skipped nothing
+            for idx, tgt in [p for p in pending if p[1] <= addr]:
+                if all(k == "|" or k == "_" for k, _ in cur[idx + 1:]):
+                    cur[idx] = ("_", 0)
+            pending = [p for p in pending if p[1] > addr]
         op = ins.split()[0]
         if op == "s_waitcnt":
             m = re.search(r"vmcnt\((\d+)\)", ins)
@@ -75,10 +93,13 @@ def kernel_streams(text):
             cur.append(("B", 0))
         elif op.startswith("s_cbranch") or op == "s_branch":
             cur.append(("|", 0))
+            mt = re.search(r"<[^>+]+\+0x([0-9a-fA-F]+)>", parts[1] if len(parts) > 1 else "")
+            if mt and addr is not None and base + int(mt.group(1), 16) > addr:
+                pending.append((len(cur) - 1, base + int(mt.group(1), 16)))
         elif re.match(r"(buffer|global|flat|scratch)_(load|store|atomic)", op):
             kind = "S" if "_store" in op else ("D" if re.search(r"\blds\b", ins) else "L")
             cur.append((kind, 1))
-    return kernels
+    return {k: [t for t in v if t[0] != "_"] for k, v in kernels.items()}
 
 
 def signature(tokens):
