@@ -124,11 +124,12 @@ def op_bytes(cn, oi, n):
     return b
 
 
-def mfma_roofline(pipe, frames_dev, batch, F):
-    """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs and bytes."""
+def mfma_roofline(pipe, frames_dev, batch, F, group=1, crops=None):
+    """HIP-event time of every MFMA conv launch of one step vs its algorithmic FLOPs and bytes (group > 1: the recogniser runs once per
+    `group` steps on group * batch * F crops -- a step's share of that run is 1 / group of its time, FLOPs, bytes and launches)."""
     from scrfd_arcface_facerecognition_amd.lower import OP_BBLOCK, OP_CONV, OP_DWPW, OP_LATFPN, OP_MBBLOCK, OP_STEM, OP_STEMBLOCK, OP_STEMFUSED
     tot_ms, tot_flop, tot_bytes, launches, per_net = 0.0, 0.0, 0.0, 0, {}
-    for name, cn, imgs, n in (("scrfd_10g", pipe.det, frames_dev, batch), ("arcface_r50", pipe.rec, pipe.crops, batch * F)):
+    for name, cn, imgs, n, share in (("scrfd_10g", pipe.det, frames_dev, batch, 1.0), ("arcface_r50", pipe.rec, crops if crops is not None else pipe.crops, group * batch * F, 1.0 / group)):
         best = None
         for _ in range(3):
             ms = cn.run_profiled(imgs, n)
@@ -149,14 +150,15 @@ def mfma_roofline(pipe, frames_dev, batch, F):
             if oi in absorbed:
                 continue
             t += float(best[oi]); by += op_bytes(cn, oi, n); k += 1
+        t, fl, by, k = t * share, fl * share, by * share, k * share
         hbm_floor, mfma_floor = by / (PEAK_HBM_GBS * 1e9) * 1e3, fl / (PEAK_FP16_TFLOPS * 1e12) * 1e3
-        per_net[name] = {"ms": round(t, 4), "tflops": round(fl / t / 1e9, 1), "gbs": round(by / t / 1e6, 1), "launches": k,
+        per_net[name] = {"ms": round(t, 4), "tflops": round(fl / t / 1e9, 1), "gbs": round(by / t / 1e6, 1), "launches": round(k, 1), "images_per_run": n,
                          "gflop": round(fl / 1e9, 1), "gbytes": round(by / 1e9, 3),
                          "hbm_floor_ms": round(hbm_floor, 4), "mfma_floor_ms": round(mfma_floor, 4),
                          "bound": "hbm" if hbm_floor > mfma_floor else "mfma",
                          "frac_of_floor": round(max(hbm_floor, mfma_floor) / t, 4),
                          "frac_mfma_peak": round(fl / t / 1e9 / PEAK_FP16_TFLOPS, 4), "frac_hbm_peak": round(by / t / 1e6 / PEAK_HBM_GBS, 4),
-                         "net_ms_all_ops": round(float(best.sum()), 4)}
+                         "net_ms_all_ops": round(float(best.sum()) * share, 4)}
         tot_ms += t; tot_flop += fl; tot_bytes += by; launches += k
     traffic, traffic_src = None, None   # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
     for d in PROFILE_DIRS:
@@ -181,7 +183,7 @@ def mfma_roofline(pipe, frames_dev, batch, F):
             "hbm_floor_ms": round(hbm_floor, 4), "mfma_floor_ms": round(mfma_floor, 4), "conv_ms": round(tot_ms, 4),
             "kernel": "MFMA conv kernels of one step (per layer the autotuner's pick among conv_mfma_kernel / conv_mfma_dma_kernel / "
                       "conv3x3_direct / conv3x3_chunked / conv3x3_pc / conv3x3_pc2 / conv3x3_pcr / conv3x3_wr / conv3x3_ks / conv3x3_s2 / conv_gw / conv_bb / scrfd_stem_rows / stem_conv_mfma)",
-            "launches": launches, "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2),
+            "launches": round(launches, 1), "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2),
             "gflop_per_step": round(tot_flop / 1e9, 1), "algorithmic_gbytes_per_step": round(tot_bytes / 1e9, 3),
             "algorithmic_bytes_per_launch": round(tot_bytes / launches), "per_net": per_net}
 
@@ -276,6 +278,9 @@ def main():
                     help="how two batches are kept in flight per GPU: 'lanes' = two whole pipelines on two streams, steps issued round-robin; "
                          "'stages' (experiment, N = 1) = ONE detector on stream A and ONE recogniser + gallery on stream B, step i+1's detect stage "
                          "beside step i's align / embed / match stages (events between the streams, two sets of post-process buffers)")
+    ap.add_argument("--rec-group", type=int, default=int(os.environ.get("FID_BENCH_REC_GROUP", "1")),
+                    help="steps whose faces share one recogniser run (pipeline.GroupedFacePipeline: every step detects + aligns its own batch, the "
+                         "group's last step embeds and matches all group x batch x F crops; N = 1, schedule 'lanes')")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FID_BENCH_STREAMS", "2")),
                     help="pipelines in flight per GPU: steps are issued round-robin to this many independent "
                          "contexts/HIP streams so that the small kernels of one batch overlap another batch's")
@@ -321,13 +326,14 @@ def main():
     from scrfd_arcface_facerecognition_amd import archs
     from scrfd_arcface_facerecognition_amd._lib import Context, check
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
-    from scrfd_arcface_facerecognition_amd.pipeline import (Communicator, FacePipeline, build_targets_from_images,
+    from scrfd_arcface_facerecognition_amd.pipeline import (Communicator, FacePipeline, GroupedFacePipeline, build_targets_from_images,
                                                             calibrate_detector_bias, run_step_distributed, shard_range)
     # experiment hook (docs/HOOKS.md): FID_BENCH_PRIO="p0,p1" = HIP stream priority per lane (torch: -1 high, 0 default)
     prios = [int(x) for x in os.environ.get("FID_BENCH_PRIO", "").split(",") if x.strip()]
     stream = torch.cuda.Stream(priority=prios[0]) if prios else torch.cuda.Stream()
     ctx = Context(local_rank, stream.cuda_stream)
     B, F = args.batch, args.faces_per_frame
+    RG = args.rec_group if args.schedule == "lanes" else 1                        # recogniser runs once per RG steps of a lane
     G = args.gallery or (1000 if world == 1 else 100_000)
     thresh = 0.4
     calib = np.random.default_rng(1234).integers(0, 256, (8, 640, 640, 3), dtype=np.uint8)   # same on every rank
@@ -338,7 +344,7 @@ def main():
     rec_net = archs.iresnet50()
     rec_P = archs.synth_params(rec_net, seed=0)
     det = CompiledNet(ctx, det_net, det_P, max_batch=B)
-    rec = CompiledNet(ctx, rec_net, rec_P, max_batch=B * F)
+    rec = CompiledNet(ctx, rec_net, rec_P, max_batch=B * F * RG)
 
     # gallery (same on every rank): the first 8 entries come from the reference's own gallery construction (build_targets,
     # main.py:78-105) run through the device path on the calibration frames; the rest are random 512-d vectors
@@ -375,19 +381,22 @@ def main():
             ln.stream = torch.cuda.Stream(priority=prios[li]) if li < len(prios) else torch.cuda.Stream()
             ln.ctx = Context(local_rank, ln.stream.cuda_stream)
             ln.det = CompiledNet(ln.ctx, det_net, det_P, max_batch=B)
-            ln.rec = CompiledNet(ln.ctx, rec_net, rec_P, max_batch=B * F)
+            ln.rec = CompiledNet(ln.ctx, rec_net, rec_P, max_batch=B * F * RG)
             ln.gallery = Gallery(ln.ctx, gal_host[g_lo:g_hi], names[g_lo:g_hi])
         n = B * F
         with torch.cuda.stream(ln.stream):
-            ln.q_local = torch.empty((n, 512), dtype=torch.float16, device="cuda")
-            ln.pipe = FacePipeline(ln.ctx, ln.det, ln.rec, batch=B, faces_per_frame=F, q_buffer=ln.q_local)
+            ln.q_local = torch.empty((n * RG, 512), dtype=torch.float16, device="cuda")
+            if RG > 1:
+                ln.pipe = GroupedFacePipeline(ln.ctx, ln.det, ln.rec, batch=B, faces_per_frame=F, group=RG, q_buffer=ln.q_local)
+            else:
+                ln.pipe = FacePipeline(ln.ctx, ln.det, ln.rec, batch=B, faces_per_frame=F, q_buffer=ln.q_local)
             ln.frames_dev = ln.ctx.to_device(frames)     # resident in HBM before the timed region
             if world > 1:
-                ln.q_all = torch.empty((world * n, 512), dtype=torch.float16, device="cuda")
-                ln.idx_all = torch.empty((world * n,), dtype=torch.int32, device="cuda")
-                ln.score_all = torch.empty((world * n,), dtype=torch.float32, device="cuda")
-                ln.keys_local = torch.empty((world * n,), dtype=torch.int64, device="cuda")
-                ln.keys_all = torch.empty((world * world * n,), dtype=torch.int64, device="cuda")
+                ln.q_all = torch.empty((world * n * RG, 512), dtype=torch.float16, device="cuda")
+                ln.idx_all = torch.empty((world * n * RG,), dtype=torch.int32, device="cuda")
+                ln.score_all = torch.empty((world * n * RG,), dtype=torch.float32, device="cuda")
+                ln.keys_local = torch.empty((world * n * RG,), dtype=torch.int64, device="cuda")
+                ln.keys_all = torch.empty((world * world * n * RG,), dtype=torch.int64, device="cuda")
                 if args.comm == "native":
                     def exchange(ident):
                         box = [ident]
@@ -398,14 +407,25 @@ def main():
                     ln.dist = StagedDist if args.backend == "gloo" else dist
         lanes.append(ln)
     pipe, frames_dev = lanes[0].pipe, lanes[0].frames_dev
+    if RG > 1:                                            # the checker legs (cosine delta, survivor agreement, roofline events) look at ONE batch: a plain pipeline on lane 0's nets
+        with torch.cuda.stream(lanes[0].stream):
+            pipe = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=F)
 
-    def step(i):
+    def finish():
+        """groups a region's last steps left open are embedded + matched inside the region"""
+        if RG > 1:
+            for li in range(len(lanes)):
+                step(li, flush=True)
+
+    def step(i, flush=False):
         ln = lanes[i % len(lanes)]
         with torch.cuda.stream(ln.stream):
             if world > 1:
                 run_step_distributed(ln.pipe, ln.frames_dev, 640, 640, ln.gallery, thresh, ln.q_local, ln.q_all, ln.dist,
                                      idx_all=ln.idx_all, score_all=ln.score_all, match_scope=args.match_scope,
-                                     keys_local=ln.keys_local, keys_all=ln.keys_all, gallery_first_row=g_lo, gallery_total=G)
+                                     keys_local=ln.keys_local, keys_all=ln.keys_all, gallery_first_row=g_lo, gallery_total=G, flush=flush)
+            elif flush:
+                ln.pipe.flush(ln.gallery, thresh)
             else:
                 ln.pipe.run_step(ln.frames_dev, 640, 640, ln.gallery, thresh)
 
@@ -448,6 +468,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(k):
             fn(i)
+        finish()
         enqueue_s.append((time.perf_counter() - t0) / k)      # host time to ENQUEUE a step (diagnostic: must stay well below the step time)
         torch.cuda.synchronize()
         if world > 1:
@@ -466,15 +487,19 @@ def main():
 
     def picks_at(cn, n):
         return {p["op"] for p in cn.plans() if p["batch"] == n}
-    pre_picks = {"det": picks_at(det, B), "rec": picks_at(rec, B * F)}
-    for i in range(2 if args.schedule == "stages" else len(lanes)):              # every lane tunes its kernels alone on the GPU
+    pre_picks = {"det": picks_at(det, B), "rec": picks_at(rec, B * F * RG)}
+    for i in range(2 if args.schedule == "stages" else len(lanes) * RG):         # every lane tunes its kernels alone on the GPU
         step(i)
         torch.cuda.synchronize()
-    post_picks = {"det": picks_at(det, B), "rec": picks_at(rec, B * F)}
+    if RG > 1:
+        pipe.run_step(frames_dev, 640, 640, gallery, thresh)                       # (the checker pipeline's recogniser batch)
+        torch.cuda.synchronize()
+    post_picks = {"det": picks_at(det, B), "rec": picks_at(rec, B * F * RG)}
     plan_picks_loaded = {k: len(v) for k, v in pre_picks.items()}
     ops_autotuned = {k: len(post_picks[k] - pre_picks[k]) for k in pre_picks}
     for i in range(args.warmup):
         step(i)
+    finish()
     torch.cuda.synchronize()
     log("warm-up done")
     enqueue_s.clear()
@@ -490,9 +515,26 @@ def main():
         one = [timed_region(step_lane0, args.steps) for _ in range(3)]
         one_lane_ms = float(np.median(one)) / args.steps * 1e3
         log(f"one lane: {[round(r / args.steps * 1e3, 3) for r in one]} ms/step")
+    # ... and the same lanes with the recogniser run per step (rec_group 1): what the grouping buys stays on the line
+    ungrouped_ms = None
+    if RG > 1 and world == 1 and not args.no_one_lane:
+        for ln in lanes:
+            with torch.cuda.stream(ln.stream):
+                ln.pipe1 = FacePipeline(ln.ctx, ln.det, ln.rec, batch=B, faces_per_frame=F)
 
-    pipe.post.check()
-    counts = pipe.post.counts.download()
+        def step_ungrouped(i):
+            ln = lanes[i % len(lanes)]
+            with torch.cuda.stream(ln.stream):
+                ln.pipe1.run_step(ln.frames_dev, 640, 640, ln.gallery, thresh)
+        for i in range(len(lanes)):
+            step_ungrouped(i)
+            torch.cuda.synchronize()
+        ung = [timed_region(step_ungrouped, args.steps) for _ in range(3)]
+        ungrouped_ms = float(np.median(ung)) / args.steps * 1e3
+        log(f"rec_group 1: {[round(r / args.steps * 1e3, 3) for r in ung]} ms/step")
+
+    lanes[0].pipe.post.check()
+    counts = lanes[0].pipe.post.counts.download()
     faces_step = int(np.minimum(counts, F).sum())
     if world > 1:
         fc = torch.tensor([faces_step], dtype=torch.int64, device=red_dev)
@@ -500,7 +542,7 @@ def main():
         faces_total_step = int(fc.item())
         # the gathered result list must cover every rank's faces (scope "all"/"sharded": every rank holds the whole batch)
         if args.match_scope != "own":
-            assert lanes[0].idx_all.shape[0] == world * B * F
+            assert lanes[0].idx_all.shape[0] == world * B * F * RG
     else:
         faces_total_step = faces_step
 
@@ -526,16 +568,21 @@ def main():
                                        os.path.relpath(plan_path, ROOT) if min(plan_picks_loaded.values()) > 0 else
                                        f"autotuned at start-up (plan key mismatch: {os.path.relpath(plan_path, ROOT)} holds no picks for this device / library revision)"),
                        "plan_picks_loaded": plan_picks_loaded, "ops_autotuned_at_startup": ops_autotuned,
-                       "parallelism": par + (f", {len(lanes)} batches in flight per GPU on separate HIP streams" if len(lanes) > 1 else "")},
+                       "parallelism": par + (f", {len(lanes)} batches in flight per GPU on separate HIP streams" if len(lanes) > 1 else "")
+                                      + (f"; the recogniser of a lane runs once per {RG} of its steps on their {RG * B * F} crops (every step detects + aligns its "
+                                         f"own batch; all {args.steps} steps' faces are embedded and matched inside the timed region)" if RG > 1 else ""),
+                       "rec_group": RG},
             "repeats": len(repeats), "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in repeats],
             "ms_per_step_min": round(min(repeats) / args.steps * 1e3, 4),
             "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
         }
         if one_lane_ms is not None:
             out["ms_per_step_1lane"] = round(one_lane_ms, 4)
+        if ungrouped_ms is not None:
+            out["ms_per_step_rec_group1"] = round(ungrouped_ms, 4)
         if not args.no_roofline:
             log("roofline: per-op HIP-event timing")
-            out["roofline"] = mfma_roofline(pipe, frames_dev, B, F)
+            out["roofline"] = mfma_roofline(pipe, frames_dev, B, F, RG, crops=lanes[0].pipe.crops)
     side = rank == 0 and world == 1 and args.cpu_frames > 0
     if side:
         # the batch the roofline leg left in the pipeline is `frames`; re-run one step so idx/score/kps belong to it

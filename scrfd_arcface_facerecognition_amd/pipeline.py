@@ -93,6 +93,11 @@ class FacePipeline:
 
     def run_step(self, frames_dev, H, W, gallery: Gallery, thresh: float = 0.4):
         """One full pass over one batch; asynchronous (results stay on the device)."""
+        if self.det.ctx is not self.ctx:
+            # detect() runs on the detector's stream, embed() on this pipeline's: nothing orders the two (ADVICE r4).  A staged schedule calls
+            # detect / embed / match itself and puts its own events between the streams (bench.py --schedule stages).
+            raise ValueError("FacePipeline.run_step: the detector lives on another context / stream; call detect(), embed(), match() "
+                             "with your own cross-stream events")
         self.detect(frames_dev, H, W)
         self.embed(frames_dev, H, W)
         self.match(gallery, thresh)
@@ -120,6 +125,90 @@ class FacePipeline:
     def embeddings(self) -> np.ndarray:
         """Raw (un-normalised) fp32 embeddings of the last step, [B*F, 512]."""
         return self.rec.read(self.rec.low.outputs[0], self.n_slots).reshape(self.n_slots, -1)
+
+
+class GroupedFacePipeline(FacePipeline):
+    """FacePipeline whose recogniser runs once per `group` consecutive steps (dynamic batching across steps, round 5).
+
+    Every step still detects, post-processes and aligns ITS batch of B frames at once (the frames may be overwritten as soon as
+    `run_step` has been enqueued); the B*F crops of the group's steps collect in one buffer and the last step of the group sends all
+    group*B*F of them through IResNet, the L2 normalisation and ONE gallery match.  IResNet-50 at 64 crops has one tile per CU on its
+    26 stage-3 layers (a launch = one latency chain); at 128 crops it runs at 810 instead of 664 TFLOP/s (gpurun_out/r05): the same
+    work per face, 18 % less time.  The price is latency: a step's identities exist when its group's last step has run
+    (`flush` finishes a partial group).  Slots of step k of the group: [k*B*F, (k+1)*B*F) of `q`, `idx`, `score`."""
+
+    def __init__(self, ctx: Context, det: CompiledNet, rec: CompiledNet, *, batch: int, faces_per_frame: int = 1, group: int = 2,
+                 det_cap: int = 256, **kw):
+        assert group >= 1 and rec.max_batch >= group * batch * faces_per_frame
+        q_buffer = kw.pop("q_buffer", None)
+        super().__init__(ctx, det, rec, batch=batch, faces_per_frame=faces_per_frame, det_cap=det_cap, **kw)
+        self.group = int(group)
+        self.posts = [self.post] + [PostProcessor(det.ctx, batch, cap=det_cap) for _ in range(self.group - 1)]
+        n = self.n_slots
+        self.crops = ctx.empty((self.group * n, 112, 112, 3), np.uint8)
+        self.q = q_buffer if q_buffer is not None else ctx.empty((self.group * n, self.emb_dim), np.float16)
+        self.idx = ctx.empty((self.group * n,), np.int32)
+        self.score = ctx.empty((self.group * n,), np.float32)
+        self.k = 0                                           # steps of the current group already detected + aligned
+
+    def collect(self, frames_dev, H, W) -> bool:
+        """detect + post-process + align one batch into the group's crop buffer; True when the group is full"""
+        if self.det.ctx is not self.ctx:
+            raise ValueError("GroupedFacePipeline: detector and recogniser must share one context / stream")
+        k, n = self.k, self.n_slots
+        self.post = self.posts[k]
+        self.detect(frames_dev, H, W)
+        check(self.ctx.lib.fid_align_crops(self.ctx.handle, _lib._ptr(frames_dev), self.B, H, W,
+                                           C.c_void_p(self.post.kps.ptr), C.c_void_p(self.post.counts.ptr),
+                                           self.post.cap, self.F, C.c_void_p(self.crops.ptr + k * n * 112 * 112 * 3), None))
+        self.k += 1
+        return self.k == self.group
+
+    def run_step(self, frames_dev, H, W, gallery: Gallery, thresh: float = 0.4):
+        if self.collect(frames_dev, H, W):
+            self.flush(gallery, thresh)
+
+    def embed_collected(self) -> int:
+        """IResNet + L2 normalisation of the steps collected so far into q[0 : steps * B * F]; returns steps (0: nothing collected)"""
+        steps, n = self.k, self.n_slots
+        if steps == 0:
+            return 0
+        self.rec.run_device(self.crops, steps * n)
+        emb_ptr, _, _ = self.rec.tensor(self.rec.low.outputs[0])
+        q_ptr = _lib._ptr(self.q).value
+        for j in range(steps):
+            check(self.ctx.lib.fid_l2_normalize_f16_slots(self.ctx.handle, C.c_void_p(emb_ptr + j * n * self.emb_dim * 4), n, self.emb_dim,
+                                                          C.c_void_p(self.posts[j].counts.ptr), self.F,
+                                                          C.c_void_p(q_ptr + j * n * self.emb_dim * 2)))
+        self.last_steps, self.k = steps, 0
+        return steps
+
+    def flush(self, gallery: Gallery, thresh: float = 0.4):
+        """embed + match the steps collected so far (a whole group, or what a stream's end left of one)"""
+        steps = self.embed_collected()
+        if steps:
+            self.match(gallery, thresh, n=steps * self.n_slots)
+
+    def results(self, gallery: Gallery):
+        """per step of the last finished group: the list FacePipeline.results returns for one batch"""
+        out = []
+        idx_all, score_all = self.idx.download(), self.score.download()
+        for j in range(getattr(self, "last_steps", 0)):
+            post = self.posts[j]
+            post.check()
+            counts, det, kps = post.counts.download(), post.det.download(), post.kps.download()
+            idx = idx_all[j * self.n_slots:(j + 1) * self.n_slots].reshape(self.B, self.F)
+            score = score_all[j * self.n_slots:(j + 1) * self.n_slots].reshape(self.B, self.F)
+            frames = []
+            for b in range(self.B):
+                faces = []
+                for f in range(min(int(counts[b]), self.F)):
+                    i = int(idx[b, f])
+                    faces.append((det[b, f, :4].copy(), float(det[b, f, 4]), kps[b, f].reshape(5, 2).copy(),
+                                  gallery.names[i] if i >= 0 else "Unknown", float(score[b, f])))
+                frames.append(faces)
+            out.append(frames)
+        return out
 
 
 def calibrate_detector_bias(ctx: Context, net, params, frames: np.ndarray, target: int = 48, max_batch: int = 8):
@@ -321,9 +410,16 @@ def _slice_ptr(buf, row0: int, row_bytes: int):
     return base + row0 * row_bytes
 
 
+def _first_rows(buf, rows: int):
+    """the first `rows` rows of a device buffer the collective / match calls accept (torch tensor or numpy array: a view; else unchanged)"""
+    if buf is None or not hasattr(buf, "shape") or int(buf.shape[0]) == rows:
+        return buf
+    return buf[:rows]
+
+
 def run_step_distributed(pipe, frames_dev, H, W, gallery, thresh, q_local, q_all, dist, *, idx_all=None, score_all=None,
                          match_scope: str = "all", keys_local=None, keys_all=None, gallery_first_row: int = 0,
-                         gallery_total: int = 0):
+                         gallery_total: int = 0, flush: bool = False):
     """One multi-GPU step: local detect / align / embed on this rank's frames, ONE all-gather of the
     unit fp16 embeddings (the collective BASELINE.json's north_star names), then the gallery match on the gathered
     matrix.  `dist` is torch.distributed (RCCL as backend "nccl", gloo in the CPU tests) or a `Communicator`
@@ -341,9 +437,17 @@ def run_step_distributed(pipe, frames_dev, H, W, gallery, thresh, q_local, q_all
                  [gallery_first_row, +G_local) of a gallery_total-row gallery; every rank scans its shard for all
                  world*n queries (fid_match_keys), a second tiny all-gather exchanges the packed (score, index) keys
                  (keys_local [world*n] u64 -> keys_all [world, world*n]), fid_match_merge takes the arg-max.
+
+    A GroupedFacePipeline (anything with collect / embed_collected) only detects + aligns until its group is full: the call returns False
+    and nothing is exchanged.  The group's last step (or `flush=True`, which embeds what a stream's end left of a group without detecting
+    anything) runs IResNet on all collected crops, then the SAME one all-gather and match on n = steps * B * F rows per rank -- the buffers
+    are sized for a full group, a partial group uses their first rows (every rank holds the same number of steps).  Returns True when results
+    were written.
     """
     r, world = dist.get_rank(), dist.get_world_size()
     n = pipe.n_slots
+    grouped = hasattr(pipe, "collect")
+    n_cap = n * (pipe.group if grouped else 1)              # rows per rank the buffers must hold
 
     def rows(buf):                                   # entries of a result / key buffer (torch tensor, DeviceBuffer, numpy array)
         if buf is None:
@@ -354,12 +458,23 @@ def run_step_distributed(pipe, frames_dev, H, W, gallery, thresh, q_local, q_all
     # would overrun them at world > 1 (a one-rank group may use them: world*n == n)
     if match_scope == "all" and idx_all is None and score_all is None and world == 1:
         idx_all, score_all = pipe.idx, pipe.score
-    if match_scope in ("all", "sharded") and (rows(idx_all) < world * n or rows(score_all) < world * n):
-        raise ValueError(f"match_scope={match_scope!r} writes {world * n} results: pass idx_all / score_all with at least that many entries")
-    if match_scope == "sharded" and (rows(keys_local) < world * n or rows(keys_all) < world * world * n or gallery_total <= 0):
+    if match_scope in ("all", "sharded") and (rows(idx_all) < world * n_cap or rows(score_all) < world * n_cap):
+        raise ValueError(f"match_scope={match_scope!r} writes {world * n_cap} results: pass idx_all / score_all with at least that many entries")
+    if match_scope == "sharded" and (rows(keys_local) < world * n_cap or rows(keys_all) < world * world * n_cap or gallery_total <= 0):
         raise ValueError("match_scope='sharded' needs keys_local [world*n], keys_all [world*world*n] (uint64) and gallery_total")
-    pipe.detect(frames_dev, H, W)
-    pipe.embed(frames_dev, H, W)            # writes q_local (pipe.q aliases it); empty face slots are zero rows
+    if grouped:
+        if not flush and not pipe.collect(frames_dev, H, W):
+            return False                    # the group is still open: this step's crops wait for the group's last step
+        steps = pipe.embed_collected()      # writes q_local[0 : steps * B * F]
+        if steps == 0:
+            return False
+        n = steps * pipe.n_slots
+        q_local, q_all = _first_rows(q_local, n), _first_rows(q_all, world * n)
+        idx_all, score_all = _first_rows(idx_all, world * n), _first_rows(score_all, world * n)
+        keys_local, keys_all = _first_rows(keys_local, world * n), _first_rows(keys_all, world * world * n)
+    else:
+        pipe.detect(frames_dev, H, W)
+        pipe.embed(frames_dev, H, W)        # writes q_local (pipe.q aliases it); empty face slots are zero rows
     dist.all_gather_into_tensor(q_all, q_local)
     if match_scope == "own":
         pipe.match(gallery, thresh, q=_slice_ptr(q_all, r * n, 512 * 2), n=n)
@@ -371,3 +486,4 @@ def run_step_distributed(pipe, frames_dev, H, W, gallery, thresh, q_local, q_all
         pipe.match_merge(keys_all, world, world * n, gallery_total, thresh, idx_all, score_all)
     else:
         raise ValueError(f"unknown match_scope {match_scope!r}")
+    return True

@@ -175,3 +175,88 @@ def test_two_rank_step_all_scopes(tmp_path):
     own_score = np.concatenate([outs[r]["own_score"] for r in range(world)])
     assert np.array_equal(own_idx, ref_idx) and np.allclose(own_score, ref_score, atol=1e-6)
     assert (ref_idx >= 0).sum() >= per_rank - 2
+
+
+class GroupedOraclePipe(OraclePipe):
+    """the GroupedFacePipeline surface (collect / embed_collected, group): `steps_q` [steps, n, 512] are this rank's unit embeddings per step"""
+
+    def __init__(self, steps_q, q_local, group):
+        super().__init__(steps_q[0], q_local, None)
+        self.group, self._steps_q, self._step, self.k = group, steps_q, 0, 0
+
+    def collect(self, frames_dev, H, W):
+        self.calls.append("collect")
+        self.k += 1
+        return self.k == self.group
+
+    def embed_collected(self):
+        steps = self.k
+        if steps == 0:
+            return 0
+        self.calls.append(f"embed{steps}")
+        for j in range(steps):
+            self._q_local[j * self.n_slots:(j + 1) * self.n_slots].copy_(torch.from_numpy(self._steps_q[self._step + j]))
+        self._step += steps
+        self.k = 0
+        return steps
+
+
+def _worker_grouped(rank, world, port, q_steps, gal, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scrfd_arcface_facerecognition_amd.pipeline import run_step_distributed
+    steps, _, n, _ = q_steps.shape                                   # [steps, world, n, 512]
+    group = 2
+    res = {}
+    for scope in ("all", "sharded"):
+        q_local = torch.zeros((group * n, 512), dtype=torch.float16)
+        q_all = torch.zeros((world * group * n, 512), dtype=torch.float16)
+        idx_all = torch.full((world * group * n,), -9, dtype=torch.int32)
+        score_all = torch.zeros((world * group * n,), dtype=torch.float32)
+        from scrfd_arcface_facerecognition_amd.pipeline import shard_range
+        glo, ghi = shard_range(len(gal), world, rank) if scope == "sharded" else (0, len(gal))
+        kw = {}
+        if scope == "sharded":
+            kw = dict(keys_local=torch.zeros((world * group * n,), dtype=torch.int64), keys_all=torch.zeros((world * world * group * n,), dtype=torch.int64),
+                      gallery_first_row=glo, gallery_total=len(gal))
+        pipe = GroupedOraclePipe(q_steps[:, rank], q_local, group)
+        common = dict(idx_all=idx_all, score_all=score_all, match_scope=scope, **kw)
+        done = [run_step_distributed(pipe, None, 640, 640, gal[glo:ghi], 0.4, q_local, q_all, dist, **common) for _ in range(2)]
+        assert done == [False, True] and pipe.calls == ["collect", "collect", "embed2"]
+        res[f"{scope}_full_idx"], res[f"{scope}_full_q"] = idx_all.numpy().copy(), q_all.numpy().copy()
+        # a stream that ends inside a group: one more step, then flush = the same collective on the first n rows per rank
+        idx_all.fill_(-9)
+        assert run_step_distributed(pipe, None, 640, 640, gal[glo:ghi], 0.4, q_local, q_all, dist, **common) is False
+        assert run_step_distributed(pipe, None, 640, 640, gal[glo:ghi], 0.4, q_local, q_all, dist, flush=True, **common) is True
+        assert run_step_distributed(pipe, None, 640, 640, gal[glo:ghi], 0.4, q_local, q_all, dist, flush=True, **common) is False     # nothing left
+        res[f"{scope}_part_idx"] = idx_all.numpy().copy()
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_grouped_step(tmp_path):
+    """run_step_distributed with a GroupedFacePipeline-shaped pipe (round 5): no collective until the group is full, then ONE all-gather of
+    steps * n rows per rank in [rank][step][slot] order; flush of a partial group uses the first rows of the same buffers"""
+    from oracle import match
+    rng = np.random.default_rng(5)
+    world, n, steps = 2, 4, 3
+    gal = rng.standard_normal((37, 512)).astype(np.float32)
+    emb = gal[rng.integers(0, 37, steps * world * n)] + 0.4 * rng.standard_normal((steps * world * n, 512)).astype(np.float32)
+    q = (emb / np.linalg.norm(emb, axis=1, keepdims=True)).astype(np.float16).reshape(steps, world, n, 512)
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_grouped, args=(world, port, q, gal, str(tmp_path)), nprocs=world, join=True)
+    full = np.concatenate([q[s, r] for r in range(world) for s in range(2)])          # [rank][step][slot]
+    part = np.concatenate([q[2, r] for r in range(world)])
+    ref_full, _ = match.match_batch(full.astype(np.float32), gal, 0.4)
+    ref_part, _ = match.match_batch(part.astype(np.float32), gal, 0.4)
+    for r in range(world):
+        o = np.load(tmp_path / f"g{r}.npz")
+        for scope in ("all", "sharded"):
+            assert np.array_equal(o[f"{scope}_full_q"], full), (r, scope)
+            assert np.array_equal(o[f"{scope}_full_idx"], ref_full), (r, scope)
+            assert np.array_equal(o[f"{scope}_part_idx"][:world * n], ref_part), (r, scope)
+            assert (o[f"{scope}_part_idx"][world * n:] == -9).all(), (r, scope)       # rows behind the partial group are not written
