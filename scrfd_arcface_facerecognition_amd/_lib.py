@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -160,6 +161,8 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise FileNotFoundError(
                     f"{LIB_PATH} not built: run `make -C {os.path.join(_HERE, 'csrc')}`; there is no CPU fallback")
+            if os.environ.get("FID_LIB"):                 # never silently: a forgotten FID_LIB would test another build's kernels
+                print(f"[faceid] FID_LIB={os.environ['FID_LIB']}: loading {LIB_PATH} instead of libfaceid.so", file=sys.stderr, flush=True)
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol

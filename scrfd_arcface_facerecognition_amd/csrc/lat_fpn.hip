@@ -288,7 +288,8 @@ __global__ void __launch_bounds__(NT, 2) lat_fpn(const LFArgs a) {
 
 // c [B, H, W, Cin_p] fp16 (Cin_p = 64 | 96), res [B, rH, rW, 64] or NULL -> out [B, H, W, 64] (+ lat [B, H, W, 64] or NULL)
 bool lat_fpn_applicable(int Cin_p, int H, int W, int rH, int rW, bool has_res) {
-    return (Cin_p == 64 || Cin_p == 96) && H >= 3 && W >= 3 && (!has_res || (rH >= (H + 1) / 2 && rW >= (W + 1) / 2));
+    // the coarser lateral is read at (y >> 1, x >> 1): only an exact 2x level is the reference PAFPN's nearest interpolation
+    return (Cin_p == 64 || Cin_p == 96) && H >= 3 && W >= 3 && (!has_res || (H == 2 * rH && W == 2 * rW));
 }
 int lat_fpn_launch(fid_ctx *ctx, const void *in, int B, int H, int W, int Cin_p, const void *w0, const float *b0, const void *res, int rH, int rW, const void *w1,
                    const float *b1, void *out, void *lat) {

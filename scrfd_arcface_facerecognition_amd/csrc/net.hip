@@ -869,7 +869,20 @@ size_t partial_need(fid_ctx *ctx, fid_net *net, int batch) {
     return std::max<size_t>(need, 256);
 }
 
+static int run_all_impl(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float *op_ms);
+
+// (the failure path too gives the tuner's flush arena back and clears the flag: a run_op error during tuning used to leave 320 MB with the
+// context until the next successful run -- ADVICE r4)
 int run_all(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float *op_ms) {
+    const int rc = run_all_impl(ctx, net, images, batch, op_ms);
+    if (rc != FID_OK && ctx && net && net->tuned_now) {
+        net->tuned_now = false;
+        (void)release_scratch(ctx, 4);
+    }
+    return rc;
+}
+
+static int run_all_impl(fid_ctx *ctx, fid_net *net, const uint8_t *images, int batch, float *op_ms) {
     FID_REQUIRE(ctx && net && images, "NULL argument");
     FID_REQUIRE(batch > 0 && batch <= net->max_batch, "batch %d outside [1, %d]", batch, net->max_batch);
     // r01's recorded SIGSEGV (gpurun_out/gpu_tests_13.log): a working tree whose fid_net_create did not size `tuned` yet indexed

@@ -185,7 +185,7 @@ def _latfpn(net, i, tensors, tid):
         return None
     if n.res is not None:
         r_t = tensors[tid[n.res]]
-        if r_t[4] != 0 or r_t[1] != 64 or r_t[2] < (src_t[2] + 1) // 2 or r_t[3] < (src_t[3] + 1) // 2:
+        if r_t[4] != 0 or r_t[1] != 64 or src_t[2] != 2 * r_t[2] or src_t[3] != 2 * r_t[3]:      # exact 2x levels only (see the CF_RES_UP2 note below)
             return None
     convs, adders = [], 0
     for j, x in enumerate(net.nodes):
@@ -375,6 +375,11 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
             b0off = blob.add(padded(b, 64))[0]
             s0off = blob.add(padded(P[st.wname + ".prelu"], 64))[0] if st.act == "prelu" else -1
             W1, bt1, _, _ = fold_conv(c1, (H0, W0))
+            # stem_block.hip is built with -fno-honor-nans (its max(v, 0) then needs no canonicalising second v_max): a folded weight or bias that
+            # is inf / NaN, or overflows fp16, would be undefined behaviour there instead of propagating -- refused here
+            for nm_, arr_ in (("stem weights", Wd), ("stem bias", b), ("conv1 weights", W1), ("conv1 bias", bt1)):
+                if not np.isfinite(np.asarray(arr_, dtype=np.float64)).all() or np.abs(np.asarray(arr_, dtype=np.float64)).max() > 65504.0:
+                    raise ValueError(f"{st.name} / {c1.name}: folded {nm_} are not finite fp16 values; the fused stem block cannot take them")
             b1t = np.zeros((bt1.shape[0], 64), dtype=np.float32)
             b1t[:, :64] = bt1
             w1off = blob.add(repack_kind2(pack_weights(W1, 64, 64)))[0]
@@ -623,6 +628,13 @@ def lower(net: Net, P: Dict[str, np.ndarray]) -> Lowered:
                 b2off = blob.add(bt2)[0]
             soff = blob.add(padded(P[n.wname + ".prelu"], cout_p))[0] if n.act == "prelu" else -1
             flags = (CF_BORDER if ncls == 9 else 0) | (CF_RES_UP2 if n.res_up2 else 0)
+            if n.res_up2:
+                # the kernels read the coarser lateral at (y >> 1, x >> 1): nearest 2x.  The reference PAFPN interpolates to the finer level's
+                # exact SIZE, which differs for odd or non-2x levels -- unpinned here (the oracle upsamples by scale 2 too), so refused
+                r_t = tensors[tid[n.res]]
+                if (ho, wo) != (2 * r_t[2], 2 * r_t[3]):
+                    raise ValueError(f"{n.name}: top-down add of a {r_t[2]}x{r_t[3]} level onto {ho}x{wo}: only exact 2x levels are supported "
+                                     "(input sizes that are multiples of 32)")
             dst = new_tensor(n.name, cout, ho, wo)
             emit(n.name, type=OP_CONV, src=tid[n.src], dst=dst, res=tid[n.res] if n.res else -1, kh=k, kw=k,
                  stride=stride, pad=pad, cin=cin, cout=cout, act=ACT[n.act], flags=flags, woff=woff,

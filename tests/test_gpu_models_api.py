@@ -195,6 +195,56 @@ def test_pipeline_matches_frame_by_frame_oracle(ctx):
                     assert name == (gallery.names[j] if j >= 0 else "Unknown")
 
 
+def test_grouped_pipeline_equals_per_step_pipeline(ctx):
+    """GroupedFacePipeline (round 5: the recogniser runs once per `group` steps on their crops): three steps of DIFFERENT frames through a
+    group of 2 -- the full group, then a partial group finished by flush() -- give per step exactly the plain FacePipeline's detections and
+    identities (same kernels on the same crops; embeddings within the fp16 plan-to-plan tolerance, the batch size may change a kernel pick)."""
+    from scrfd_arcface_facerecognition_amd import archs
+    from scrfd_arcface_facerecognition_amd.engine import CompiledNet, Gallery
+    from scrfd_arcface_facerecognition_amd.pipeline import FacePipeline, GroupedFacePipeline, calibrate_detector_bias
+    rng = np.random.default_rng(18)
+    B, F, G = 3, 2, 2
+    steps = [rng.integers(0, 256, (B, 320, 320, 3), dtype=np.uint8) for _ in range(3)]
+    steps[1][1] = 0                                                   # a frame without a face inside the group
+    det_net = archs.scrfd_500m((320, 320))
+    det_P, _ = calibrate_detector_bias(ctx, det_net, archs.synth_params(det_net, 2), steps[0], target=30, max_batch=B)
+    rec_net = archs.mobilefacenet()
+    rec_P = archs.synth_params(rec_net, 2)
+    gal = rng.standard_normal((29, 512)).astype(np.float32)
+    det = CompiledNet(ctx, det_net, det_P, max_batch=B)
+    rec = CompiledNet(ctx, rec_net, rec_P, max_batch=G * B * F)
+    gallery = Gallery(ctx, gal)
+    plain = FacePipeline(ctx, det, rec, batch=B, faces_per_frame=F)
+    ref = []
+    for fr in steps:
+        plain.run_step(ctx.to_device(fr), 320, 320, gallery, thresh=0.02)
+        ref.append((plain.results(gallery), plain.q.download().copy()))
+    grp = GroupedFacePipeline(ctx, det, rec, batch=B, faces_per_frame=F, group=G)
+    dev = [ctx.to_device(fr) for fr in steps]
+    grp.run_step(dev[0], 320, 320, gallery, thresh=0.02)
+    assert grp.k == 1                                                 # collected, nothing embedded yet
+    grp.run_step(dev[1], 320, 320, gallery, thresh=0.02)
+    assert grp.k == 0
+    got = grp.results(gallery)
+    q = grp.q.download()
+    grp.run_step(dev[2], 320, 320, gallery, thresh=0.02)
+    grp.flush(gallery, thresh=0.02)
+    got += grp.results(gallery)
+    q = np.concatenate([q, grp.q.download()[:B * F]])
+    assert len(got) == 3
+    for s in range(3):
+        assert len(got[s]) == B
+        for b in range(B):
+            assert len(got[s][b]) == len(ref[s][0][b])
+            for (bb, sc, kp, name, sim), (rbb, rsc, rkp, rname, rsim) in zip(got[s][b], ref[s][0][b]):
+                assert np.array_equal(bb, rbb) and sc == rsc and np.array_equal(kp, rkp)
+                assert abs(sim - rsim) < 2e-3 and (name == rname or abs(rsim - 0.02) < 3e-3)
+        qs, qr = q[s * B * F:(s + 1) * B * F].astype(np.float32), ref[s][1].astype(np.float32)
+        assert np.array_equal(qs == 0, qr == 0)                      # the same empty / degenerate slots (incl. the -0.0 marker's magnitude)
+        assert np.abs(qs - qr).max() < 2e-3
+    assert len(got[1][1]) == 0
+
+
 def test_build_targets_matches_reference_semantics(ctx, tmp_path, caplog):
     """a19, reference main.py:78-105: per gallery image detect(max_num=1) -> skip + warn when no face -> embed the best face
     -> (embedding, name) with name = filename[:-4], in listing order.  Checked against the frame-by-frame oracle

@@ -296,7 +296,7 @@ def test_truncated_blob_is_refused(ctx, arch, hw, monkeypatch):
     import ctypes as C
     from scrfd_arcface_facerecognition_amd import _lib
     from scrfd_arcface_facerecognition_amd._lib import FaceIdError, check
-    from scrfd_arcface_facerecognition_amd.lower import (OP_BBLOCK, OP_CONV, OP_DWPW, OP_MBBLOCK, OP_STEMFUSED, lower)
+    from scrfd_arcface_facerecognition_amd.lower import (OP_BBLOCK, OP_CONV, OP_DWPW, OP_LATFPN, OP_MBBLOCK, OP_STEMBLOCK, OP_STEMFUSED, lower)
     if arch == "scrfd_500m":
         monkeypatch.setenv("FID_DWPW_FUSE", "1")             # so that the table holds OP_DWPW records too
     net = archs.ARCHS[arch](hw)
@@ -311,7 +311,8 @@ def test_truncated_blob_is_refused(ctx, arch, hw, monkeypatch):
         return h
     h = create(len(low.blob))                                # the complete blob is accepted
     check(ctx.lib.fid_net_destroy(ctx.handle, h))
-    words = {OP_STEMFUSED: (20, 21, 22, 23, 24, 25), OP_BBLOCK: (20, 21, 22, 23, 24), OP_DWPW: (20, 21, 22), OP_MBBLOCK: (20, 21, 22, 24, 25, 28)}
+    words = {OP_STEMFUSED: (20, 21, 22, 23, 24, 25), OP_BBLOCK: (20, 21, 22, 23, 24), OP_DWPW: (20, 21, 22), OP_MBBLOCK: (20, 21, 22, 24, 25, 28),
+             OP_STEMBLOCK: (20, 21, 22), OP_LATFPN: (20, 21)}      # (round 4's fused ops: W_S_W1 / B1 / S1, W_L_W0 / B0 -- ADVICE r4)
     cuts, kinds = set(), set()
     for op in ops:
         t = int(op[0])
@@ -322,6 +323,9 @@ def test_truncated_blob_is_refused(ctx, arch, hw, monkeypatch):
     assert len(cuts) > 10
     if arch == "arcface_r50":
         assert (OP_CONV, 29) in kinds and (OP_BBLOCK, 22) in kinds
+        assert (OP_STEMBLOCK, 20) in kinds and (OP_STEMBLOCK, 21) in kinds
+    if arch == "scrfd_10g":
+        assert (OP_LATFPN, 20) in kinds and (OP_LATFPN, 21) in kinds
     if arch == "arcface_mbf":
         assert (OP_MBBLOCK, 20) in kinds and (OP_MBBLOCK, 28) in kinds
     if arch == "scrfd_500m":
