@@ -123,20 +123,23 @@ def test_arcface_r50_embeddings(ctx):
     assert cosine(r[0], r[1]) < 0.999
 
 
+@pytest.mark.parametrize("table", ["arcface_mbf", "arcface_mbf_small"])
 @pytest.mark.parametrize("fusion", ["bottleneck", "dwpw", "none"])
-def test_arcface_mbf_embeddings(ctx, monkeypatch, fusion):
-    """bottleneck (default): each of the 16 blocks as one launch (csrc/mbf_block.hip); dwpw: every depthwise layer fused with the pointwise
-    conv behind it (csrc/dwpw.hip; opt-in, FID_DWPW_FUSE=1); none: layer by layer"""
+def test_arcface_mbf_embeddings(ctx, monkeypatch, fusion, table):
+    """bottleneck (default): each of the 29 (w600k_mbf's size-pinned table, round 5) / 15 (the rounds 1-4 table) blocks as one launch
+    (csrc/mbf_block.hip); dwpw: every depthwise layer fused with the pointwise conv behind it (csrc/dwpw.hip; opt-in, FID_DWPW_FUSE=1);
+    none: layer by layer"""
     from scrfd_arcface_facerecognition_amd import lower
     monkeypatch.delenv("FID_DWPW_FUSE", raising=False)
     if fusion != "bottleneck":
         monkeypatch.setenv("FID_NO_MBF_FUSE", "1")
     if fusion == "dwpw":
         monkeypatch.setenv("FID_DWPW_FUSE", "1")
-    net = archs.mobilefacenet()
+    net = archs.ARCHS[table]()
     P = archs.synth_params(net, seed=0)
     kinds = [int(r[0]) for r in lower.lower(net, P).ops]
-    assert (kinds.count(8), kinds.count(7)) == {"bottleneck": (15, 0), "dwpw": (0, 16), "none": (0, 0)}[fusion]
+    nb, ndw = (29, 29) if table == "arcface_mbf" else (15, 16)
+    assert (kinds.count(8), kinds.count(7)) == {"bottleneck": (nb, 0), "dwpw": (0, ndw), "none": (0, 0)}[fusion]
     images = np.random.default_rng(12).integers(0, 256, (2, 112, 112, 3), dtype=np.uint8)
     got, ref = run_both(ctx, net, P, images, ["fc"])
     e, r = got["fc"].reshape(2, 512), ref["fc"].reshape(2, 512)
