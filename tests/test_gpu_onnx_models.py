@@ -79,3 +79,79 @@ def test_arcface_from_onnx_file(ctx, tmp_path, basename, arch, fold_bn):
     feats = r.get_feat([crop, crop[:, ::-1].copy()])
     # (another batch size picks other kernels / fp32 summation orders: equal to fp16 noise, not bit for bit)
     assert feats.shape == (2, 512) and 1 - float(feats[0] @ emb / np.linalg.norm(feats[0]) / np.linalg.norm(emb)) < 1e-4
+
+
+# ---- f-1 by STRUCTURE: graphs whose depths, widths and head layouts are in NO table of archs.py, written with node patterns the
+# five round-trip files above do not use, loaded through the reference's constructors.  The device result is compared with the fp32 oracle evaluated
+# on the READER's IR and parameters (session.net / session.params: what onnx_reader made of the file) AND with the oracle on the graph the file was
+# written from -- a reader that mis-converts consistently would pass the first and fail the second.
+def _det_variants():
+    return [
+        ("v_det_a", lambda: archs.scrfd_resnet("v_det_a", (320, 320), stem=16, planes=(32, 64, 64, 96), blocks=(1, 2, 1, 2), neck=32, head_ch=64,
+                                               head_convs=2, head_shared=False), dict(fold_bn=False, dynamic_reshape=True, upsample="sizes")),
+        ("v_det_b", lambda: archs.scrfd_resnet("v_det_b", (320, 320), stem=20, planes=(40, 72, 72, 120), blocks=(2, 1, 2, 1), neck=40, head_ch=48,
+                                               head_convs=4, head_shared=True), dict(fold_bn=True, dynamic_reshape=False, upsample="op9")),
+    ]
+
+
+def _rec_variants():
+    return [
+        ("v_mbf_a", lambda: archs.mobilefacenet(blocks=(1, 2, 3, 1)), dict(fold_bn=False, slope_rank=4)),
+        ("v_mbf_b", lambda: archs.mobilefacenet(blocks=(3, 1, 2, 2)), dict(fold_bn=True, slope_rank=3)),
+        ("v_ir_a", lambda: archs.iresnet50(layers=(2, 1, 3, 1), name="v_ir_a"), dict(fold_bn=False, slope_rank=4)),
+    ]
+
+
+def _not_a_table(net):
+    """no table of archs.py has this graph's (kind, channels, kernel, stride) sequence"""
+    sig = [(n.kind, getattr(n, "cin", 0), getattr(n, "cout", 0), getattr(n, "k", 0), getattr(n, "stride", 0)) for n in net.nodes]
+    for f in archs.ARCHS.values():
+        t = f(net.in_hw) if net.nodes[-1].kind == "dethead" else f()
+        if sig == [(n.kind, getattr(n, "cin", 0), getattr(n, "cout", 0), getattr(n, "k", 0), getattr(n, "stride", 0)) for n in t.nodes]:
+            return False
+    return True
+
+
+@pytest.mark.parametrize("variant", range(2))
+def test_scrfd_variant_graph_from_onnx_file(ctx, tmp_path, variant):
+    from models import SCRFD
+    base, make, kw = _det_variants()[variant]
+    net = make()
+    assert _not_a_table(net)
+    P = archs.synth_params(net, seed=21 + variant)
+    path = tmp_path / f"{base}.onnx"
+    path.write_bytes(export(net, P, **kw))
+    d = SCRFD(str(path), input_size=(320, 320), conf_thres=0.5)
+    rnet, rP = d.session.net, d.session.params
+    assert [n.kind for n in rnet.nodes].count("dethead") == 3 and len(d.output_names) == 9
+    img = np.random.default_rng(40 + variant).integers(0, 256, (1, 320, 320, 3), dtype=np.uint8)
+    heads = d.session.run_images(img)
+    blob = oalign.blob_from_images(list(img), rnet.in_scale, rnet.in_mean)
+    for which, (n_, p_) in {"reader": (rnet, rP), "source": (net, P)}.items():
+        ref = onets.run_net(n_, p_, blob)
+        for li, name in enumerate(n_.outputs):
+            sc, bb, kp = ref[name]
+            assert np.abs(heads[li] - sc[0]).max() < 3e-3, (which, name)
+            assert np.abs(heads[3 + li] - bb[0]).max() < 3e-2, (which, name)
+            assert np.abs(heads[6 + li] - kp[0]).max() < 3e-2, (which, name)
+
+
+@pytest.mark.parametrize("variant", range(3))
+def test_arcface_variant_graph_from_onnx_file(ctx, tmp_path, variant):
+    from models import ArcFace
+    base, make, kw = _rec_variants()[variant]
+    net = make()
+    assert _not_a_table(net)
+    P = archs.synth_params(net, seed=25 + variant)
+    path = tmp_path / f"{base}.onnx"
+    path.write_bytes(export(net, P, **kw))
+    r = ArcFace(str(path))
+    rnet, rP = r.session.net, r.session.params
+    assert rnet.in_hw == (112, 112) and abs(rnet.in_scale - 1 / 127.5) < 1e-12
+    crops = np.random.default_rng(50 + variant).integers(0, 256, (3, 112, 112, 3), dtype=np.uint8)
+    feats = r.get_feat(list(crops))
+    blob = oalign.blob_from_images(list(crops), rnet.in_scale, rnet.in_mean)
+    for which, (n_, p_) in {"reader": (rnet, rP), "source": (net, P)}.items():
+        ref = onets.run_net(n_, p_, blob)[n_.outputs[0]].reshape(3, 512)
+        for i in range(3):
+            assert 1 - float(feats[i] @ ref[i] / np.linalg.norm(feats[i]) / np.linalg.norm(ref[i])) < 1e-3, (which, i)

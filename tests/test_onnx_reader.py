@@ -60,3 +60,34 @@ def test_model_path_dispatch(tmp_path):
     assert lower(net2, P2).blob == lower(net, P).blob
     with pytest.raises(FileNotFoundError):
         resolve_model(str(tmp_path / "missing.onnx"))
+
+
+# graphs that are in no table of archs.py, with node patterns the round trips above do not use: the reader converts by structure
+VARIANTS = [
+    ("v_det_a", lambda: archs.scrfd_resnet("v_det_a", (96, 96), stem=16, planes=(32, 64, 64, 96), blocks=(1, 2, 1, 2), neck=32, head_ch=64, head_convs=2,
+                                           head_shared=False), dict(fold_bn=False, dynamic_reshape=True, upsample="sizes")),
+    ("v_det_b", lambda: archs.scrfd_resnet("v_det_b", (96, 96), stem=20, planes=(40, 72, 72, 120), blocks=(2, 1, 2, 1), neck=40, head_ch=48, head_convs=4,
+                                           head_shared=True), dict(fold_bn=True, upsample="op9")),
+    ("v_mbf_a", lambda: archs.mobilefacenet(blocks=(1, 2, 3, 1)), dict(fold_bn=False, slope_rank=4)),
+    ("v_mbf_b", lambda: archs.mobilefacenet(blocks=(3, 1, 2, 2)), dict(fold_bn=True)),
+    ("v_ir_a", lambda: archs.iresnet50(layers=(2, 1, 3, 1), name="v_ir_a"), dict(fold_bn=False, slope_rank=4)),
+]
+
+
+@pytest.mark.parametrize("variant", range(len(VARIANTS)))
+def test_reader_converts_graphs_outside_the_tables(variant):
+    """depths / widths / head layouts of no table; BN unfolded or folded; PRelu slopes [1, C, 1, 1]; Resize by target size and the opset-9 Upsample;
+    the head's Reshape fed by Shape -> Gather -> Unsqueeze -> Concat.  The fp32 oracle on the reader's IR equals the oracle on the source graph."""
+    from oracle import align as oalign
+    base, make, kw = VARIANTS[variant]
+    net = make()
+    P = archs.synth_params(net, seed=11 + variant)
+    rnet, rP = onnx_to_ir(export(net, P, **kw), base)
+    assert len(rnet.nodes) == len(net.nodes) and [n.kind for n in rnet.nodes] == [n.kind for n in net.nodes]
+    assert abs(rnet.in_scale - net.in_scale) < 1e-12 and rnet.in_hw == net.in_hw
+    img = np.random.default_rng(variant).integers(0, 256, (1,) + net.in_hw + (3,), dtype=np.uint8)
+    blob = oalign.blob_from_images(list(img), net.in_scale, net.in_mean)
+    a, b = onets.run_net(net, P, blob), onets.run_net(rnet, rP, blob)
+    for x, y in zip(net.outputs, rnet.outputs):
+        for u, v in zip(a[x] if isinstance(a[x], tuple) else (a[x],), b[y] if isinstance(b[y], tuple) else (b[y],)):
+            assert np.abs(u - v).max() <= 1e-5 * max(1.0, float(np.abs(u).max()))

@@ -69,7 +69,10 @@ def value_info(name, shape):
     return _str(1, name) + _ld(2, _ld(1, ttype))
 
 
-def export(net, P, fold_bn=False, batch_dim=1):
+def export(net, P, fold_bn=False, batch_dim=1, dynamic_reshape=False, upsample="scales", slope_rank=3):
+    """dynamic_reshape: a detector output's Reshape takes its shape from a Shape -> Gather -> Unsqueeze -> Concat chain ([N, -1, C]: the form
+    dynamic-batch exports have) instead of a constant [-1, C]; upsample: "scales" (Resize with a scales input), "sizes" (Resize with the
+    target size as 4th input) or "op9" (the opset-9 Upsample node); slope_rank: PRelu slopes as [C, 1, 1] (3) or [1, C, 1, 1] (4)."""
     nodes, inits = [], []
     uid = [0]
 
@@ -87,6 +90,8 @@ def export(net, P, fold_bn=False, batch_dim=1):
         nodes.append(node("BatchNormalization", [x] + names, [y], name=y, epsilon=float(BN_EPS)))
         return y
 
+    from scrfd_arcface_facerecognition_amd.archs import infer_shapes
+    shapes = infer_shapes(net)
     t = {"input": "input.1"}
     H, W = net.in_hw
     outputs = []
@@ -122,7 +127,14 @@ def export(net, P, fold_bn=False, batch_dim=1):
                 if n.res_up2:
                     u = fresh("resize")
                     sc = init(fresh("scales"), np.array([1, 1, 2, 2], np.float32))
-                    nodes.append(node("Resize", [r, "", sc], [u], name=u, mode="nearest"))
+                    if upsample == "op9":
+                        nodes.append(node("Upsample", [r, sc], [u], name=u, mode="nearest"))
+                    elif upsample == "sizes":
+                        hh, ww = shapes[n.name][1], shapes[n.name][2]
+                        sz = init(fresh("sizes"), np.array([batch_dim, n.cout, hh, ww], np.int64))
+                        nodes.append(node("Resize", [r, "", "", sz], [u], name=u, mode="nearest"))
+                    else:
+                        nodes.append(node("Resize", [r, "", sc], [u], name=u, mode="nearest"))
                     r = u
                 z = fresh("add")
                 nodes.append(node("Add", [y, r], [z], name=z))
@@ -133,7 +145,7 @@ def export(net, P, fold_bn=False, batch_dim=1):
                 y = z
             elif n.act == "prelu":
                 z = fresh("prelu")
-                nodes.append(node("PRelu", [y, init(fresh(n.name + ".slope"), P[n.wname + ".prelu"].reshape(-1, 1, 1))], [z], name=z))
+                nodes.append(node("PRelu", [y, init(fresh(n.name + ".slope"), P[n.wname + ".prelu"].reshape((-1, 1, 1) if slope_rank == 3 else (1, -1, 1, 1)))], [z], name=z))
                 y = z
             t[n.name] = y
         elif n.kind == "maxpool":
@@ -173,13 +185,21 @@ def export(net, P, fold_bn=False, batch_dim=1):
                 z = fresh("transpose")
                 nodes.append(node("Transpose", [y], [z], name=z, perm=[0, 2, 3, 1]))
                 o = fresh("out_" + part)
-                nodes.append(node("Reshape", [z, init(fresh("shape"), np.array([-1, c], np.int64))], [o], name=o))
+                if dynamic_reshape:
+                    sh, g, u2, cat = fresh("shape_of"), fresh("gather"), fresh("unsq"), fresh("concat")
+                    nodes.append(node("Shape", [z], [sh], name=sh))
+                    nodes.append(node("Gather", [sh, init(fresh("idx"), np.array(0, np.int64))], [g], name=g, axis=0))
+                    nodes.append(node("Unsqueeze", [g], [u2], name=u2, axes=[0]))
+                    nodes.append(node("Concat", [u2, init(fresh("m1"), np.array([-1], np.int64)), init(fresh("cc"), np.array([c], np.int64))], [cat], name=cat, axis=0))
+                    nodes.append(node("Reshape", [z, cat], [o], name=o))
+                else:
+                    nodes.append(node("Reshape", [z, init(fresh("shape"), np.array([-1, c], np.int64))], [o], name=o))
                 head_out[{"cls": "score"}.get(part, part)].append(o)
         else:
             raise ValueError(n.kind)
     if head_out["score"]:
         outputs = head_out["score"] + head_out["bbox"] + head_out["kps"]
-        out_infos = [value_info(o, ["N", c]) for o, c in zip(outputs, [1] * 3 + [4] * 3 + [10] * 3)]
+        out_infos = [value_info(o, ["N", "A", c] if dynamic_reshape else ["N", c]) for o, c in zip(outputs, [1] * 3 + [4] * 3 + [10] * 3)]
     else:
         outputs = [t[net.outputs[0]]]
         out_infos = [value_info(outputs[0], [batch_dim, 512])]
