@@ -182,7 +182,8 @@ def mfma_roofline(pipe, frames_dev, batch, F, group=1, crops=None):
             "achieved_gbs_algorithmic": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
             "hbm_floor_ms": round(hbm_floor, 4), "mfma_floor_ms": round(mfma_floor, 4), "conv_ms": round(tot_ms, 4),
             "kernel": "MFMA conv kernels of one step (per layer the autotuner's pick among conv_mfma_kernel / conv_mfma_dma_kernel / "
-                      "conv3x3_direct / conv3x3_chunked / conv3x3_pc / conv3x3_pc2 / conv3x3_pcr / conv3x3_wr / conv3x3_ks / conv3x3_s2 / conv_gw / conv_bb / scrfd_stem_rows / stem_conv_mfma)",
+                      "conv3x3_direct / conv3x3_chunked / conv3x3_pc / conv3x3_pc2 / conv3x3_pcr / conv3x3_wr / conv3x3_ks (both also on STRIP tiles) / "
+                      "conv3x3_s2 / conv_gw, and the fused launches conv_bb / conv_bb32 / scrfd_stem_rows / ir_stem_block / lat_fpn / mbf_block / stem_conv_mfma)",
             "launches": round(launches, 1), "avg_us_per_launch": round(tot_ms * 1e3 / launches, 2),
             "gflop_per_step": round(tot_flop / 1e9, 1), "algorithmic_gbytes_per_step": round(tot_bytes / 1e9, 3),
             "algorithmic_bytes_per_launch": round(tot_bytes / launches), "per_net": per_net}
@@ -235,23 +236,55 @@ def cosine_delta(pipe, frames, rec_net, rec_P, gal_host, thresh, n_check):
             "match_index_agreement": f"{agree}/{n_check}", "cosine_delta_sample": f"{n_check} faces of the timed batch vs the fp32 oracle on identical landmarks"}
 
 
-def detector_agreement(pipe, frames, det_net, det_P, n_frames):
-    """reference models/scrfd.py:140-156 on the fp32 oracle's heads vs the device's fp16 heads of the timed batch (oracle/agreement.py):
-    survivors matched by IoU >= 0.9; a flip is marginal when one quantity within 5e-3 of a decision boundary explains it (score vs
-    conf_thres, suppressing IoU vs iou_thres, score order of an overlapping pair), a cascade when it follows from such a flip."""
+def detector_agreement(pipe, frames, det_net, det_P, rec_net, rec_P, n_frames, n_e2e=16):
+    """reference models/scrfd.py:140-177 on the fp32 oracle's heads vs the device's fp16 heads of the timed batch (oracle/agreement.py):
+    (1) NMS survivors matched by IoU >= 0.9; a flip is marginal when one quantity within 5e-3 of a decision boundary explains it (score vs
+    conf_thres, suppressing IoU vs iou_thres, score order of an overlapping pair), a cascade when it follows from such a flip;
+    (2) the face the pipeline EMBEDS (max_num = 1: the survivor of largest area, scrfd.py:159-177 + main.py:130-134): same / marginal (two
+    rivals' areas within 1e-2, or the pick is itself an explained flip of (1)) / unexplained, and for frames with the same pick the
+    END-TO-END embedding delta: device embedding (device landmarks, device crop, fp16 net) vs the oracle's (oracle landmarks from the fp32
+    heads, oracle crop, fp32 net); (3) the head margins: max |device - oracle| per stride over the frames."""
     import torch
-    from oracle import agreement as oagree, align as oalign, nets as onets
+    from oracle import agreement as oagree, align as oalign, nets as onets, pipeline as opipe, postprocess as pp
     torch.set_num_threads(host_cores())
     fused = [pipe.det.read(name, pipe.B) for name in det_net.outputs]
-    per_frame = []
+    emb = pipe.embeddings()
+    per_frame, top1, same_frames = [], {"same": 0, "marginal": 0, "unexplained": 0, "empty": 0}, []
+    err = {k: [0.0, 0.0, 0.0] for k in ("score", "bbox", "kps")}
     for fi in range(n_frames):
         blob = oalign.blob_from_images([frames[fi]], det_net.in_scale, det_net.in_mean)
         ref_outs = onets.scrfd_session_outputs(det_net, det_P, blob)
-        per_frame.append(oagree.survivor_agreement(ref_outs, oagree.fused_to_session_outputs(fused, fi), (640, 640), pipe.conf, pipe.iou, margin=5e-3))
+        dev_outs = oagree.fused_to_session_outputs(fused, fi)
+        for gi, key in enumerate(("score", "bbox", "kps")):
+            for li in range(3):
+                err[key][li] = max(err[key][li], float(np.abs(np.asarray(ref_outs[3 * gi + li]) - dev_outs[3 * gi + li]).max()))
+        a = oagree.survivor_agreement(ref_outs, dev_outs, (640, 640), pipe.conf, pipe.iou, margin=5e-3)
+        per_frame.append(a)
+        v, ia, ib = oagree.top1_agreement(a)
+        top1[v] += 1
+        if v == "same":
+            same_frames.append((fi, ref_outs))
     a = oagree.summarize(per_frame)
+    worst = 0.0
+    for fi, ref_outs in same_frames[:n_e2e]:
+        _, okps = pp.detect_from_heads(ref_outs, (640, 640), (640, 640), pipe.conf, pipe.iou, 1)
+        ref, _ = opipe.embed(frames[fi], okps[0], rec_net, rec_P)
+        e = emb[fi * pipe.F]
+        worst = max(worst, 1.0 - float(ref @ e / np.linalg.norm(ref) / np.linalg.norm(e)))
+    strides = ("s8", "s16", "s32")
     return {"det_survivor_agreement": {"matched": a["matched"], "marginal_flips": a["marginal_flips"], "cascade_flips": a["cascade_flips"],
                                        "unexplained": a["unexplained"], "survivors_oracle": a["survivors_a"], "survivors_device": a["survivors_b"],
-                                       "sample": f"all NMS survivors (max_num = 0) of {n_frames} frames of the timed batch, fp32 oracle heads vs device heads, margin 5e-3"}}
+                                       "sample": f"all NMS survivors (max_num = 0) of {n_frames} frames of the timed batch, fp32 oracle heads vs device heads, margin 5e-3"},
+            "top1_face_agreement": {"same": top1["same"], "marginal": top1["marginal"], "unexplained": top1["unexplained"], "no_face": top1["empty"],
+                                    "sample": f"the face max_num = 1 keeps (largest-area survivor) on {n_frames} frames of the timed batch: fp32 oracle heads vs "
+                                              "device heads; marginal = the rivals' areas within 1e-2 or the pick is an explained flip of det_survivor_agreement"},
+            "embed_cosine_delta_end_to_end_max": round(worst, 6),
+            "embed_cosine_delta_end_to_end_sample": f"{min(n_e2e, len(same_frames))} frames with the same pick: device embedding (device landmarks and crop) vs "
+                                                    "the oracle's (fp32 heads -> landmarks -> crop -> fp32 net)",
+            "head_score_err_max": dict(zip(strides, (round(x, 6) for x in err["score"]))),
+            "head_bbox_err_max": dict(zip(strides, (round(x, 5) for x in err["bbox"]))),
+            "head_kps_err_max": dict(zip(strides, (round(x, 5) for x in err["kps"]))),
+            "head_err_note": f"max |device - fp32 oracle| over {n_frames} frames; score = sigmoid output (test bound 4e-3 at 640 x 640), bbox / kps in stride units (3e-2)"}
 
 
 def main():
@@ -591,7 +624,7 @@ def main():
         log("cosine delta vs the oracle")
         out.update(cosine_delta(pipe, frames, rec_net, rec_P, gal_host, thresh, n_check=min(16, B)))
         log("detector survivor agreement vs the oracle")
-        out.update(detector_agreement(pipe, frames, det_net, det_P, n_frames=min(args.agree_frames, B)))
+        out.update(detector_agreement(pipe, frames, det_net, det_P, rec_net, rec_P, n_frames=min(args.agree_frames, B)))
     if side and not args.no_side_legs:
         torch.cuda.synchronize()
         # ---- side leg 1: H2D included.  Per lane two device frame buffers and one pinned host batch; the upload of the next

@@ -113,7 +113,8 @@ def survivor_agreement(outs_a, outs_b, input_size=(640, 640), conf_thres=0.5, io
             if any(verdict.get((other, j)) is not None for j in flips):
                 verdict[(side, i)] = "cascade"; changed = True
     detail = [(s, int(i), v or "unexplained") for (s, i), v in sorted(verdict.items())]
-    return {"survivors_a": int(len(det_a)), "survivors_b": int(len(det_b)), "matched": int((pair_a >= 0).sum()),
+    return {"det_a": det_a, "det_b": det_b, "pair_a": pair_a, "pair_b": pair_b,
+            "survivors_a": int(len(det_a)), "survivors_b": int(len(det_b)), "matched": int((pair_a >= 0).sum()),
             "marginal_flips": sum(1 for _, _, v in detail if v.startswith("marginal")),
             "cascade_flips": sum(1 for _, _, v in detail if v == "cascade"),
             "unexplained": sum(1 for _, _, v in detail if v == "unexplained"), "detail": detail}
@@ -125,3 +126,43 @@ def summarize(per_frame):
     out = {k: int(sum(d[k] for d in per_frame)) for k in keys}
     out["frames"] = len(per_frame)
     return out
+
+
+def _area(d):
+    return (d[:, 2] - d[:, 0]) * (d[:, 3] - d[:, 1])                  # scrfd.py:160 (no +1 here)
+
+
+def top1_agreement(agree, area_tol=1e-2, match_iou=0.9):
+    """Which face does the pipeline EMBED?  reference scrfd.py:159-177 with max_num = 1, metric "max": of the NMS survivors the one of largest
+    box AREA (main.py:130-134 then aligns and embeds exactly that face).  `agree` = survivor_agreement's result for the frame (a = fp32
+    oracle heads, b = device heads).  Verdicts:
+
+      same         both sides pick counterparts of each other (IoU >= match_iou)
+      marginal     the picks differ and either (1) on one side the two rivals' areas are within `area_tol` (relative): a box error of the size
+                   the fp16 heads carry (3e-2 stride units on a box of tens of pixels) reorders them, or (2) one side's pick has no counterpart
+                   on the other side and survivor_agreement explains that flip (marginal / cascade)
+      unexplained  anything else -- the tests assert there is none
+      empty        neither side has a survivor (no face to embed); one side only: judged like (2)
+
+    Returns (verdict, index of a's pick or -1, index of b's pick or -1)."""
+    det_a, det_b, pair_a, pair_b = agree["det_a"], agree["det_b"], agree["pair_a"], agree["pair_b"]
+    why = {(s_, i): v for s_, i, v in agree["detail"]}
+    if len(det_a) == 0 and len(det_b) == 0:
+        return "empty", -1, -1
+    ia = int(np.argsort(_area(det_a), kind="stable")[::-1][0]) if len(det_a) else -1
+    ib = int(np.argsort(_area(det_b), kind="stable")[::-1][0]) if len(det_b) else -1
+    if ia >= 0 and ib >= 0 and pair_a[ia] == ib:
+        return "same", ia, ib
+
+    def explained(side, i):
+        return i < 0 or why.get((side, i), "unexplained") != "unexplained"
+    if ia < 0 or ib < 0:
+        return ("marginal" if explained("a", ia) and explained("b", ib) and (ia < 0 or pair_a[ia] < 0) and (ib < 0 or pair_b[ib] < 0) else "unexplained"), ia, ib
+    ja, jb = int(pair_a[ia]), int(pair_b[ib])                          # a's pick as b sees it, b's pick as a sees it
+    if ja < 0 or jb < 0:                                              # a pick that the other side does not have at all
+        ok = (ja >= 0 or explained("a", ia)) and (jb >= 0 or explained("b", ib))
+        return ("marginal" if ok else "unexplained"), ia, ib
+    ar_a, ar_b = _area(det_a), _area(det_b)
+    close_a = abs(float(ar_a[ia]) - float(ar_a[jb])) <= area_tol * float(ar_a[ia])      # on side a: its pick vs b's pick
+    close_b = abs(float(ar_b[ib]) - float(ar_b[ja])) <= area_tol * float(ar_b[ib])
+    return ("marginal" if close_a or close_b else "unexplained"), ia, ib

@@ -65,3 +65,45 @@ def test_gross_change_is_unexplained():
         if r["unexplained"] >= 1:
             return
     raise AssertionError("no gross change was reported as unexplained")
+
+
+def test_top1_agreement_classifies_the_embedded_face():
+    """reference scrfd.py:159-177 (max_num = 1: the survivor of largest area is the face main.py:130-134 embeds): identical heads pick the same
+    face, fp16-sized perturbations never produce an unexplained pick, growing another face's box by 30 % does"""
+    rng = np.random.default_rng(7)
+    outs = _heads(rng)
+    r = ag.survivor_agreement(outs, [o.copy() for o in outs])
+    v, ia, ib = ag.top1_agreement(r)
+    assert v == "same" and ia == ib >= 0
+    d1, _ = ag.pp.detect_from_heads(outs, (640, 640), (640, 640), 0.5, 0.4, 1)
+    assert np.array_equal(d1[0], r["det_a"][ia])                      # the checker's pick IS detect(max_num=1)'s
+    verdicts = []
+    for seed in range(12):
+        rng = np.random.default_rng(100 + seed)
+        outs = _heads(rng)
+        pert = [o + rng.normal(0, 8e-4, o.shape).astype(np.float32) * (1.0 if i < 3 else 4.0) for i, o in enumerate(outs)]
+        verdicts.append(ag.top1_agreement(ag.survivor_agreement(outs, pert))[0])
+    assert "unexplained" not in verdicts and verdicts.count("same") >= 9, verdicts
+    # gross: on side b another survivor's box grows well past the area of a's pick
+    outs = _heads(np.random.default_rng(7))
+    r = ag.survivor_agreement(outs, [o.copy() for o in outs])
+    _, ia, _ = ag.top1_agreement(r)
+    areas = (r["det_a"][:, 2] - r["det_a"][:, 0]) * (r["det_a"][:, 3] - r["det_a"][:, 1])
+    other = int(np.argsort(areas)[-3])                                 # a clearly smaller survivor
+    assert areas[other] < 0.97 * areas[ia]
+    r2 = dict(r)
+    det_b = r["det_b"].copy()
+    j = int(r["pair_a"][other])
+    cx, cy = (det_b[j, 0] + det_b[j, 2]) / 2, (det_b[j, 1] + det_b[j, 3]) / 2
+    w, h = (det_b[j, 2] - det_b[j, 0]) * 1.02, (det_b[j, 3] - det_b[j, 1]) * 1.02     # (IoU with its counterpart stays >= 0.9)
+    scale = np.sqrt(1.3 * areas[ia] / (w * h))
+    r2["det_b"] = det_b
+    # keep the pairing (the checker is given one), enlarge the box so that it wins the area arg-max on side b
+    det_b[j, :4] = [cx - w * scale / 2, cy - h * scale / 2, cx + w * scale / 2, cy + h * scale / 2]
+    v, ia2, ib2 = ag.top1_agreement(r2)
+    assert ia2 == ia and ib2 == j and v == "unexplained"
+
+
+def test_top1_agreement_without_faces():
+    e = np.zeros((0, 5), np.float32)
+    assert ag.top1_agreement({"det_a": e, "det_b": e, "pair_a": np.zeros(0, int), "pair_b": np.zeros(0, int), "detail": []})[0] == "empty"

@@ -109,7 +109,7 @@ def test_full_size_properties(plan, monkeypatch):
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     fused = [det.read(name, B) for name in det_net.outputs]
     cnt_all, det_all, kps_all = pipe2.post.counts.download()[:B], pipe2.post.det.download(), pipe2.post.kps.download()
-    per_frame, worst64 = [], [0.0, 0.0, 0.0]
+    per_frame, worst64, top1, e2e = [], [0.0, 0.0, 0.0], {"same": 0, "marginal": 0, "unexplained": 0, "empty": 0}, []
     for fi in range(B):
         dev_outs = oagree.fused_to_session_outputs(fused, fi)
         od, ok = opp.detect_from_heads(dev_outs, (640, 640), (640, 640), 0.5, 0.4, 0)
@@ -119,12 +119,30 @@ def test_full_size_properties(plan, monkeypatch):
         blob = oalign.blob_from_images([frames[fi]], det_net.in_scale, det_net.in_mean)
         ref_outs = onets.scrfd_session_outputs(det_net, det_P, blob)
         per_frame.append(oagree.survivor_agreement(ref_outs, dev_outs, (640, 640), 0.5, 0.4, margin=5e-3))
+        # the face the pipeline EMBEDS (reference scrfd.py:159-177 with max_num = 1 + main.py:130-134): the oracle's pick on
+        # the fp32 heads vs the device's pick; the device's own max_num = 1 result (first pipeline, `dets`) is that pick bit for bit
+        verdict, ia, ib = oagree.top1_agreement(per_frame[-1])
+        top1[verdict] += 1
+        assert ib >= 0 and np.array_equal(dets[fi, 0], per_frame[-1]["det_b"][ib]), fi
+        if verdict == "same" and len(e2e) < 6:
+            _, okps1 = opp.detect_from_heads(ref_outs, (640, 640), (640, 640), 0.5, 0.4, 1)
+            oe, _ = opipe.embed(frames[fi], okps1[0], rec_net, rec_P)                      # oracle end to end: fp32 heads -> landmarks -> crop -> fp32 net
+            e2e.append(1 - float(oe @ emb[fi] / np.linalg.norm(oe) / np.linalg.norm(emb[fi])))
         for li in range(3):                                           # session outputs 0..2 = the three strides' scores
             worst64[li] = max(worst64[li], float(np.abs(np.asarray(dev_outs[li], np.float32) - ref_outs[li]).max()))
     agree = oagree.summarize(per_frame)
     print(f"\ndet_survivor_agreement (plan={plan}): {agree}; worst |score - oracle| over all {B} frames per stride: " + " ".join(f"{v:.2e}" for v in worst64))
     assert agree["unexplained"] == 0, [(fi, d["detail"]) for fi, d in enumerate(per_frame) if d["unexplained"]]
     assert agree["matched"] >= 0.9 * agree["survivors_a"], agree
+    line = (f"plan={plan}: det_survivor_agreement {agree}; top1_face_agreement {top1}; end-to-end embed cosine delta on {len(e2e)} same-pick frames "
+            f"max {max(e2e):.2e}; head_score_err_max s8 / s16 / s32 over {B} frames " + " / ".join(f"{v:.3e}" for v in worst64))
+    print("\n" + line)
+    out_dir = os.path.join(ROOT, "gpurun_out")                         # (pytest -q swallows stdout: the margins are kept as a file -- VERDICT r4 item 6)
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "fullsize_margins.txt"), "a") as f:
+        f.write(line + "\n")
+    assert top1["unexplained"] == 0 and top1["same"] >= 0.8 * B, top1
+    assert max(e2e) < 2e-3, e2e          # (device landmarks differ from the oracle's by the fp16 head error: 3e-2 stride units = a fraction of a pixel of the crop)
     n0 = int(pipe2.post.counts.download()[0])
     d0 = pipe2.post.det.download()[0, :n0]
     assert n0 >= 1
