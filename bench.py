@@ -311,7 +311,7 @@ def main():
                     help="how two batches are kept in flight per GPU: 'lanes' = two whole pipelines on two streams, steps issued round-robin; "
                          "'stages' (experiment, N = 1) = ONE detector on stream A and ONE recogniser + gallery on stream B, step i+1's detect stage "
                          "beside step i's align / embed / match stages (events between the streams, two sets of post-process buffers)")
-    ap.add_argument("--rec-group", type=int, default=int(os.environ.get("FID_BENCH_REC_GROUP", "1")),
+    ap.add_argument("--rec-group", type=int, default=int(os.environ.get("FID_BENCH_REC_GROUP", "2")),
                     help="steps whose faces share one recogniser run (pipeline.GroupedFacePipeline: every step detects + aligns its own batch, the "
                          "group's last step embeds and matches all group x batch x F crops; N = 1, schedule 'lanes')")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("FID_BENCH_STREAMS", "2")),

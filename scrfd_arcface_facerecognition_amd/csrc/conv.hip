@@ -872,6 +872,7 @@ static std::vector<ConvPlan> conv_candidates_all(const ConvArgs &a, int num_cus,
         if (conv_strip_ok(a)) {                        // the same on x-packed STRIP tiles (round 5): ns = 8 streaming, 9 resident
             d.ns = 8; d.bm = 512; d.bn = 128; out.push_back(d);
             d.bm = 256; d.bn = 64; out.push_back(d);
+            if (a.Cout_p > 64) { d.bm = 256; d.bn = 128; out.push_back(d); }     // one tile x 128 couts (eight waves)
             if (conv_wr_resident_ok(a)) { d.bm = 256; d.bn = a.Cout_p; d.ns = 9; out.push_back(d); }
             d.ns = 0;
         }

@@ -747,7 +747,7 @@ bool conv_wr_resident_ok(const ConvArgs &a) {
 int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident, int ring, bool strip) {
     FID_REQUIRE(c.w_alt, "conv3x3_wr needs the fragment-order weights (repack kind 2)");
     FID_REQUIRE(!strip || (conv_strip_ok(c) && ring != 4), "conv3x3_wr: no STRIP tiling for a %d-wide map (ring %d)", c.W, ring);
-    FID_REQUIRE(resident ? conv_wr_resident_ok(c) : ((nt == 2 && cb == 128) || (nt == 1 && cb == 64)), "conv3x3_wr: no %d x %d variant (resident %d)", nt, cb, resident);
+    FID_REQUIRE(resident ? conv_wr_resident_ok(c) : ((nt == 2 && cb == 128) || (nt == 1 && cb == 64) || (nt == 1 && cb == 128 && strip)), "conv3x3_wr: no %d x %d variant (resident %d)", nt, cb, resident);
     // tile edge 14 or 16: whichever computes fewer pixels for this map (14 fits IResNet's 112 / 56 / 28 / 14 maps exactly and a 40x40
     // map in 3x3 tiles of 196 = 91 % useful pixels, where 16x16 tiles compute 48x48 for 69 %)
     auto padded = [&](int t) { return (long long)cdiv(c.H, t) * t * cdiv(c.W, t) * t; };
@@ -806,6 +806,10 @@ int conv_wr_launch(fid_ctx *ctx, const ConvArgs &c, int nt, int cb, int resident
     if (strip) {
         const bool one = c.H == 14 && TH == 14;                // the map is one tile high: the two halo rows are skipped
         if (nt == 2) return TH == 14 ? (one ? wr_launch_t<14, 2, 8, 0, 2, 3>(ctx, a, a.n_tiles) : wr_launch_t<14, 2, 8, 0, 2, 1>(ctx, a, a.n_tiles)) : wr_launch_t<16, 2, 8, 0, 2, 1>(ctx, a, a.n_tiles);
+        if (cb == 128) {                                       // one tile x 128 couts on eight waves: a quarter of the pair item's work, the epilogue and prologue of ONE item where conv3x3_ks pays two
+            if (TH == 10) return wr_launch_t<10, 1, 8, 0, 2, 1>(ctx, a, a.n_tiles);
+            return TH == 14 ? (one ? wr_launch_t<14, 1, 8, 0, 2, 3>(ctx, a, a.n_tiles) : wr_launch_t<14, 1, 8, 0, 2, 1>(ctx, a, a.n_tiles)) : wr_launch_t<16, 1, 8, 0, 2, 1>(ctx, a, a.n_tiles);
+        }
         if (TH == 10) return wr_launch_t<10, 1, 4, 0, 2, 1>(ctx, a, a.n_tiles);
         return TH == 14 ? (one ? wr_launch_t<14, 1, 4, 0, 2, 3>(ctx, a, a.n_tiles) : wr_launch_t<14, 1, 4, 0, 2, 1>(ctx, a, a.n_tiles)) : wr_launch_t<16, 1, 4, 0, 2, 1>(ctx, a, a.n_tiles);
     }

@@ -639,7 +639,7 @@ int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first,
                 if (const char *fn = getenv("FID_FORCE_NS")) {       // tests: one ring variant of generation 2 / 5
                     std::vector<ConvPlan> only;
                     for (const ConvPlan &c : cands)
-                        if (((c.gen == 2 || c.gen == 5 || c.gen == 12) && c.ns == atoi(fn)) || (c.gen == 9 && (c.ns == 1 ? 3 : (c.ns == 4 ? 4 : (c.ns == 6 ? (c.bm == 512 ? 7 : 6) : (c.ns >= 7 ? c.ns + 1 + (c.ns == 8 && c.bm == 512 ? 20 : 0) : c.bm / 256)))) == atoi(fn))) only.push_back(c);
+                        if (((c.gen == 2 || c.gen == 5 || c.gen == 12) && c.ns == atoi(fn)) || (c.gen == 9 && (c.ns == 1 ? 3 : (c.ns == 4 ? 4 : (c.ns == 6 ? (c.bm == 512 ? 7 : 6) : (c.ns >= 7 ? c.ns + 1 + (c.ns == 8 && c.bm == 512 ? 20 : 0) + (c.ns == 8 && c.bm == 256 && c.bn == 128 ? 30 : 0) : c.bm / 256)))) == atoi(fn))) only.push_back(c);
                     if (!only.empty()) cands = only;
                 }
                 const float pc2_bias = getenv("FID_PC2_BIAS") ? (float)atof(getenv("FID_PC2_BIAS")) : 1.f;

@@ -37,8 +37,8 @@ def forced_ran(cn, code):
             return p["gen"] == 9 and p["ns"] == 6 and p["bm"] == (256 if code == 96 else 512)
         if code == 98:                                          # conv_ks on x-packed STRIP tiles
             return p["gen"] == 9 and p["ns"] == 7
-        if code in (909, 929):                                  # conv_wr on STRIP tiles: one tile x 64 couts / a pair x 128 couts
-            return p["gen"] == 9 and p["ns"] == 8 and p["bm"] == (256 if code == 909 else 512)
+        if code in (909, 929, 939):                             # conv_wr on STRIP tiles: one tile x 64 couts / a pair x 128 couts / one tile x 128 couts
+            return p["gen"] == 9 and p["ns"] == 8 and (p["bm"], p["bn"]) == {909: (256, 64), 929: (512, 128), 939: (256, 128)}[code]
         if code == 910:                                         # conv_wr on STRIP tiles, the layer's weights resident
             return p["gen"] == 9 and p["ns"] == 9
         return p["gen"] == code
@@ -66,7 +66,7 @@ def stack(hw, chans, res=True):
 # 98 = conv_ks on x-packed STRIP tiles (round 5): a tile is 16 consecutive columns of the strip of all images' rows (the (14, 14) x 5 case: 70 strip
 #      columns = four full tiles and one of six lanes; (37, 21): every one of 21 boundary positions inside a tile)
 # 909 / 929 / 910 = conv_wr on STRIP tiles (one tile x 64 couts / a pair of tiles x 128 couts / the resident-weight variant)
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 91, 92, 93, 94, 96, 97, 98, 909, 929, 910, 11, 25, 51, 59])
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7, 8, 91, 92, 93, 94, 96, 97, 98, 909, 929, 939, 910, 11, 25, 51, 59])
 @pytest.mark.parametrize("hw,chans,batch", [((32, 48), (64, 96), 3), ((28, 28), (128, 256), 5), ((40, 24), (88, 224), 2), ((37, 21), (64, 64), 3),
                                             ((14, 14), (128, 128), 5), ((20, 20), (64, 96), 4), ((20, 20), (224, 224), 3)])
 def test_conv_family(ctx, monkeypatch, gen, hw, chans, batch):
@@ -127,7 +127,7 @@ def test_conv_mosaic_7x7(ctx, monkeypatch, gen, chans, batch):
 
 # STRIP tiles (round 5): x-packed pixel fragments -- image counts that fill / do not fill the last tile, a single image, maps of one / two / three
 # tile rows, every lane position of the image boundary (21-wide rows), plain / border-class bias, PReLU, residual; against the oracle
-@pytest.mark.parametrize("gen", [98, 909, 929, 910])
+@pytest.mark.parametrize("gen", [98, 909, 929, 939, 910])
 @pytest.mark.parametrize("hw,chans,batch", [((14, 14), (128, 128), 8), ((14, 14), (64, 256), 9), ((14, 14), (128, 64), 1), ((14, 14), (64, 128), 17),
                                             ((28, 28), (128, 128), 3), ((20, 20), (64, 192), 5), ((12, 12), (64, 64), 6), ((15, 15), (128, 64), 4),
                                             ((37, 21), (64, 128), 3), ((40, 40), (64, 64), 2), ((56, 56), (64, 128), 3), ((40, 40), (96, 96), 3),
@@ -150,6 +150,10 @@ def test_conv_strip(ctx, monkeypatch, gen, hw, chans, batch):
     elif gen == 98 and any(c % 64 for c in chans):
         if not ran:
             pytest.skip("conv_ks needs an even number of 32-channel chunks")
+    elif gen == 939:
+        if max(chans) <= 64:
+            pytest.skip("one tile x 128 couts: layers with more than 64 couts")
+        assert len(ran) >= 1, ran
     else:
         assert len(ran) >= 2, ran                          # at least the convs on the second channel count
     ref = onets.run_net(net, P, align.blob_from_images(list(images), net.in_scale, net.in_mean))[net.outputs[0]]
