@@ -40,6 +40,10 @@ int release_scratch(fid_ctx *ctx, int slot) {
 // hipFuncSetAttribute acts on the thread's CURRENT device: set the context's first, or a thread that drives contexts on two devices
 // records the attribute as done for one device while having set it on the other
 int ensure_dyn_lds(fid_ctx *ctx, const void *func, int bytes) {
+    // FID_KLOG=1 (tools/klog_map.py): name the kernel every launcher is about to launch -- with net.hip's "[klog] op" lines the map op -> kernel
+    // that turns a profiler's per-kernel MFMA instruction counts into executed / algorithmic work per kernel
+    static const bool klog = getenv("FID_KLOG") != nullptr;
+    if (klog) fprintf(stderr, "[klog] kernel %s\n", hipKernelNameRefByPtr(func, ctx->stream));
     static std::mutex mu;
     static std::map<std::pair<const void *, int>, int> set_bytes;
     std::lock_guard<std::mutex> lk(mu);

@@ -499,6 +499,8 @@ int set_alt_weights(fid_ctx *ctx, fid_net *net, int oi, ConvArgs &a, const ConvP
 int run_op(fid_ctx *ctx, fid_net *net, int oi, const uint8_t *images, int first, int batch, void *partial_ws) {
     const int32_t *op = &net->ops[(size_t)oi * FID_OP_WORDS];
     const char *blob = (const char *)net->blob;
+    static const bool klog = getenv("FID_KLOG") != nullptr;
+    if (klog) fprintf(stderr, "[klog] op %d\n", oi);
     const TensorView dst = view(net, op[W_DST], first);
     images += (size_t)first * net->in_h * net->in_w * 3;
     const float *bias = op[W_BOFF] >= 0 ? (const float *)(blob + op[W_BOFF]) : nullptr;

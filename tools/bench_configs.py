@@ -89,6 +89,8 @@ def run(name):
         return run_cfg4()
     if name == "cfg4x1":
         return run_cfg4(lanes=1)
+    if name == "cfg4c585":                          # chunks of 585 crops = 512 STRIP tiles of 14 x 16 on IResNet's 14x14 stage: two full rounds of pair items on 256 CUs
+        return run_cfg4(chunk=585)
     c = CFG[name]
     ctx = Context(0)
     det_net = archs.ARCHS[c["det"]]()
@@ -118,5 +120,5 @@ def run(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CFG) + ["cfg4"]):
+    for n in (sys.argv[1:] or list(CFG) + ["cfg4", "cfg4c585"]):
         run(n)

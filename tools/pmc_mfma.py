@@ -42,6 +42,12 @@ def durations(run_dir):
 
 def main():
     out = sys.argv[1]
+    # optional: tools/klog_map.py's JSON + the number of net runs the profiled program made -> executed / algorithmic MFMA work per kernel
+    alg, runs = {}, 0
+    if len(sys.argv) > 3:
+        import json
+        alg = json.load(open(sys.argv[2]))["gflop_per_run_by_kernel"]
+        runs = int(sys.argv[3])
     a, na = load(os.path.join(out, "a"))
     dur = durations(os.path.join(out, "a"))
     b, _ = load(os.path.join(out, "b"))
@@ -62,9 +68,21 @@ def main():
     rows.sort(reverse=True)
     tot = sum(r[0] for r in rows)
     print("clk_ghz = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration (kernel trace of the same pass): the shader clock the chip held while the kernel ran")
-    print(f"{'kernel':56s} {'launches':>8s} {'time%':>6s} {'avg_us':>8s} {'clk_ghz':>7s} {'mfma_util':>9s} {'mfma_chip':>9s} {'wait':>6s} {'istall':>6s} {'active':>6s} {'lds_st':>6s} {'bankcf':>6s} {'mfma_insts':>12s} {'valu':>6s} {'lds':>6s} {'salu':>6s}   (valu / lds / salu = SQ_ACTIVE_INST_* of the second pass over SQ_WAVE_CYCLES of the first)")
+    if alg:
+        print(f"executed_over_algorithmic = SQ_INSTS_MFMA x 16 384 flop (v_mfma_f32_16x16x32_f16; kernels that also issue 16x16x16 steps -- ir_stem_block, scrfd_stem_rows -- are over-counted by those) "
+              f"/ (algorithmic GFLOP per run of the kernel's ops, tools/klog_map.py, x {runs} runs of the net in the profiled program)")
+    print(f"{'kernel':56s} {'launches':>8s} {'time%':>6s} {'avg_us':>8s} {'clk_ghz':>7s} {'mfma_util':>9s} {'mfma_chip':>9s} {'wait':>6s} {'istall':>6s} {'active':>6s} {'lds_st':>6s} {'bankcf':>6s} {'mfma_insts':>12s} {'valu':>6s} {'lds':>6s} {'salu':>6s} {'exec/alg':>8s} {'alg_TF/s':>8s}   (valu / lds / salu = SQ_ACTIVE_INST_* of the second pass over SQ_WAVE_CYCLES of the first)")
+    busy_w, t_w = 0.0, 0.0
     for gui, k, n, mu, mc, w, ws, ac, wl, bc, ni, clk, avg, va, la, sa in rows[:40]:
-        print(f"{k[:56]:56s} {n:8d} {100 * gui / tot:6.1f} {avg:8.1f} {clk:7.2f} {100 * mu:9.1f} {100 * mc:9.1f} {100 * w:6.1f} {100 * ws:6.1f} {100 * ac:6.1f} {100 * wl:6.1f} {100 * bc:6.1f} {ni:12.0f} {100 * va:6.1f} {100 * la:6.1f} {100 * sa:6.1f}")
+        ea, tf = "", ""
+        if alg.get(k) and runs:
+            ea = f"{ni * 16384 / (alg[k] * 1e9 * runs):8.3f}"
+            tf = f"{alg[k] * runs / (avg * n * 1e-6) / 1e3:8.1f}"
+        if ni > 0:
+            busy_w += mu * gui; t_w += gui
+        print(f"{k[:56]:56s} {n:8d} {100 * gui / tot:6.1f} {avg:8.1f} {clk:7.2f} {100 * mu:9.1f} {100 * mc:9.1f} {100 * w:6.1f} {100 * ws:6.1f} {100 * ac:6.1f} {100 * wl:6.1f} {100 * bc:6.1f} {ni:12.0f} {100 * va:6.1f} {100 * la:6.1f} {100 * sa:6.1f} {ea:>8s} {tf:>8s}")
+    if t_w:
+        print(f"time-weighted MFMA-busy of the kernels that issue MFMAs: {100 * busy_w / t_w:.1f} %")
 
 
 if __name__ == "__main__":

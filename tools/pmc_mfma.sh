@@ -15,6 +15,13 @@ echo "pass a done"
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA \
     --output-format csv -d $O/b -o p -- python3 $R/$1 "${@:2}" > $O/b.log 2>&1
 echo "pass b done"
-python3 $R/tools/pmc_mfma.py $O > $O/summary.txt
+# KLOG="arch batch runs": also the executed / algorithmic MFMA work per kernel (tools/klog_map.py: op -> kernel map of that net at that batch; runs = net runs of the profiled program)
+if [ -n "$KLOG" ]; then
+  set -- $KLOG
+  (cd $R && python3 tools/klog_map.py $1 $2 > $O/klog_map.json 2> $O/klog_map.err) || true
+  python3 $R/tools/pmc_mfma.py $O $O/klog_map.json $3 > $O/summary.txt
+else
+  python3 $R/tools/pmc_mfma.py $O > $O/summary.txt
+fi
 rm -f $O/*/*counter_collection.csv $O/*/*kernel_trace.csv $O/*/*/*counter_collection.csv $O/*/*/*kernel_trace.csv
 cat $O/summary.txt
