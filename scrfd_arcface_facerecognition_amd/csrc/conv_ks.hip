@@ -16,8 +16,12 @@
 // them into one image.  The rows of ALL images of the batch laid side by side form a strip of B * W columns, and a tile is TH rows x 16 CONSECUTIVE
 // STRIP COLUMNS: on a 14-wide map eight images are seven exact fragments (a 14-column tile leaves lanes 14, 15 idle: 1.14 x the matrix work), on
 // 28 / 56 / 112 / 20 / 40-wide maps likewise.  A tile crosses at most one image boundary (host-checked): lanes behind it belong to the next image
-// and read one patch position further right, so that ONE shared zero column (the right padding of image A = the left padding of image B) sits
-// between the two images in the patch (PW = 19).  Row-sharing, the tap order and every counted wait are unchanged; what changes is the
+// and read GW patch positions further right: the right padding of image A and the left padding of image B sit between the two images in the
+// patch.  GW = 1 (one shared zero column, PW = 19) breaks the bank pattern of the fragment reads -- the 16 pixels of a fragment are no longer 16
+// CONSECUTIVE 64-byte positions, so one 256-byte bank row gets five of them: SQ_LDS_BANK_CONFLICT 47 % of the LDS cycles against 5 % (profiles/r05).
+// GW = 8 (PW = 26) moves the lanes behind the boundary by 512 bytes: the same bank row quarter and the same XOR swizzle as without the gap --
+// conflict-free again; used wherever the patch slots still fit (maps one tile high store only their TH real rows).
+// Row-sharing, the tap order and every counted wait are unchanged; what changes is the
 // piece -> pixel mapping of the patch fetch, a per-item lane shift in the fragment addresses, and the lane -> pixel mapping of the epilogue.
 #include <type_traits>
 
@@ -65,12 +69,25 @@ struct KSArgs {
 // dropped), so one 16-pixel matrix column carries two images and an item's 64 x 9 Cin weights serve four images instead of one.
 // MODE 2 (the map is one tile high, H = TH -- IResNet's 14x14 stage): patch rows 0 and TH + 1 lie outside the image: zeros, not multiplied.
 // STRIP (MODE & 4): see the head of the file; MODE 6 = STRIP on a map one tile high.
+// gap between a STRIP tile's two images: 8 positions (conflict-free fragment reads) where two patch slots of two chunks each + the K-half exchange
+// area fit the 160 KB (10-row tiles; 14-row tiles of maps one tile high, which store 14 patch rows), else the one shared zero column
+// MEASURED (profiles/r05/ab_gutter8.txt, same box, two alternations): the conflict-free 8-position gap is NOT faster -- IResNet-50 at batch 500
+// 6.40 -> 6.46 ms, at 128 and SCRFD-10G +-0: the seven extra positions per row are seven more 64-byte cells every LDS-DMA piece list carries (19 -> 23 KB
+// per tile and chunk, one more piece per wave and step), and the fragment reads were not what the step waits for.  Default: the one shared column;
+// `make EXTRA=-DFID_STRIP_GW=8` builds the wide gap.
+#ifndef FID_STRIP_GW
+#define FID_STRIP_GW 1
+#endif
+constexpr int ks_gutter(int th, int mode) { return (FID_STRIP_GW == 8 && (th == 10 || (mode & 3) == 2)) ? 8 : 1; }
 template <int TH, int MODE>
 __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
     constexpr bool MOSAIC = (MODE & 3) == 1, ONE_ROW = (MODE & 3) == 2, STRIP = (MODE & 4) != 0;
     static_assert(!(STRIP && MOSAIC), "one packing at a time");
-    constexpr int PW = STRIP ? 19 : 18;
-    constexpr int TW = STRIP ? 16 : TH, PH = TH + 2, NPIX = PH * PW, RH = TH / 2;
+    constexpr int GW = STRIP ? ks_gutter(TH, MODE) : 0;        // patch positions between the tile's two images
+    constexpr int PW = 18 + GW;
+    constexpr bool COMPACT = STRIP && ONE_ROW && GW == 8;       // the two halo rows are never read: the slot holds patch rows 1 .. TH only (what lets the wide gap fit)
+    constexpr int R0 = COMPACT ? 1 : 0;
+    constexpr int TW = STRIP ? 16 : TH, PH = TH + 2, NPIX = (COMPACT ? TH : PH) * PW, RH = TH / 2;
     constexpr int P_BLKS = (NPIX * 64 + 1023) / 1024, P_BYTES = P_BLKS * 1024, SLOT = KS * P_BYTES, NS = 2;
     constexpr int N_PIECES = KS * P_BLKS, MAX_P = (N_PIECES + NWT - 1) / NWT;
     constexpr int EX_BYTES = NWT * RH * 1024;                    // one KB per (wave, handed-over row)
@@ -145,7 +162,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
             const int j = wave + NWT * k;
             int pk = p_pk[k];
             asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
-            const int py = pk & 255, iy = c.y0 + py, ix = c.x0 + ((pk >> 8) & 255);
+            const int py = pk & 255, iy = c.y0 + py + R0, ix = c.x0 + ((pk >> 8) & 255);
             bool in;
             unsigned vo;
             if (MOSAIC) {
@@ -153,8 +170,8 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
                 in = c.n >= 0 && py != 255 && (unsigned)iy < 16u && (unsigned)ix < 16u && ly < 7 && lx < 7 && img < a.n_img && !(a.ablate & 2);
                 vo = in ? (unsigned)((((img * 7 + ly) * 7 + lx) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
             } else if (STRIP) {                                 // position p holds image A's column x0 + p up to its right padding (column W), behind it image B from column 0
-                const bool second = ix > a.W;
-                const int img = c.n + (second ? 1 : 0), lx = second ? ix - a.W - 1 : ix;
+                const bool second = ix > a.W;                   // (positions W + 1 .. W + GW - 2 of a wide gap are never read; W + GW - 1 is image B's left padding)
+                const int img = c.n + (second ? 1 : 0), lx = second ? ix - a.W - GW : ix;
                 in = c.n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H && (unsigned)lx < (unsigned)a.W && img < a.n_img && !(a.ablate & 2);
                 vo = in ? (unsigned)((((img * a.H + iy) * a.W + lx) * a.Cin_p + c0 + (pk >> 16)) * 2) : OOB;
             } else {
@@ -196,7 +213,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
         decode_tile(tile < a.n_tiles ? tile : 0, n, ty, c0);
         int fr = frow;
         asm volatile("" : "+v"(fr));
-        set_pbase(fr + (fr >= a.W - c0 ? 1 : 0));
+        set_pbase(fr + (fr >= a.W - c0 ? GW : 0));
     };
 
     f32x4 acc[TH];
@@ -212,7 +229,7 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
             }
         half8 pq[PD + 1];
         auto load_p = [&](int q, int set) {                     // q = dx * PH + patch row
-            const int K = (q % PH) * PW + q / PH;               // lin = K + frow
+            const int K = (q % PH - R0) * PW + q / PH;          // lin = K + frow
             pq[set] = *(const half8 *)(smem + (pb[K & 1][(K >> 1) & 3] + K * 64));
         };
         // MOSAIC: patch rows 0, 8, 16, 17 (the halo above / below and the two gutters) are zeros and output rows 7, 15 are dropped:
@@ -437,8 +454,8 @@ __global__ void __launch_bounds__(NWT * 64, 2) conv3x3_ks(const KSArgs a) {
 
 template <int TH, int MODE = 0>
 static int ks_launch_t(fid_ctx *ctx, KSArgs &a, int per_wg) {
-    constexpr int PW = (MODE & 4) ? 19 : 18;
-    constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
+    constexpr int PW = 18 + ((MODE & 4) ? ks_gutter(TH, MODE) : 0);
+    constexpr int P_BYTES = ((((MODE & 7) == 6 && PW == 26 ? TH : TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     const int LDS = 2 * KS * P_BYTES + 1024 + NWT * (TH / 2) * 1024 + (a.ncls + 1) * CBW * 4;
     FID_REQUIRE(LDS <= 160 * 1024, "conv3x3_ks: %d bytes of LDS", LDS);
     FID_TRY(ensure_dyn_lds(ctx, (const void *)conv3x3_ks<TH, MODE>, LDS));

@@ -37,6 +37,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB = 0x7FFFFFF0u;
+#ifndef FID_STRIP_GW
+#define FID_STRIP_GW 1
+#endif
+constexpr int WR_STRIP_GW = FID_STRIP_GW == 8 ? 8 : 1;           // patch positions between a STRIP tile's two images
 constexpr int CK = 32;                                            // channels per step (patch width: 18 positions, 19 with STRIP tiles)
 
 __device__ __forceinline__ int swz64(int lin) { return (lin >> 1) & 3; }
@@ -80,9 +84,16 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
     constexpr bool STRIP = (XF & 1) != 0, ONE_ROW = (XF & 2) != 0;
     static_assert(!ONE_ROW || NCH == 0, "ONE_ROW: streaming variants only (the deferred write-out is scheduled on the full row list)");
     constexpr int CBW = NW * 16;                                // couts per item
-    constexpr int PW = STRIP ? 19 : 18;                         // patch positions per row (STRIP: one shared zero column between the tile's two images)
+    // STRIP: GW = 8 patch positions between the tile's two images: the lanes behind the boundary read 512 bytes further right -- the same bank row
+    // quarter and XOR swizzle as without the gap, so the fragment reads stay conflict-free (one shared zero column, GW = 1, put five of a fragment's
+    // sixteen pixels on one bank row: 33-50 % of the LDS cycles were conflicts, profiles/r05); maps one tile high store only their TH real rows
+    // MEASURED equal-to-slower (conv_ks.hip, profiles/r05/ab_gutter8.txt): the default is the one shared zero column, GW = 1; -DFID_STRIP_GW=8 builds the gap
+    constexpr int GW = STRIP ? WR_STRIP_GW : 0;
+    constexpr int PW = 18 + GW;                                 // patch positions per row
+    constexpr bool COMPACT = STRIP && ONE_ROW && GW == 8;
+    constexpr int R0 = COMPACT ? 1 : 0;
     constexpr int TW = STRIP ? 16 : TH;                         // tile stride in x (16 lanes per fragment; lanes >= TW are not stored)
-    constexpr int PH = TH + 2, NPIX = PH * PW;
+    constexpr int PH = TH + 2, NPIX = (COMPACT ? TH : PH) * PW;
     constexpr int P_BLKS = (NPIX * 64 + 1023) / 1024, P_BYTES = P_BLKS * 1024, SLOT = NT * P_BYTES;
     constexpr int MAX_P = (NT * P_BLKS + NW - 1) / NW;          // patch pieces per wave and step
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,12 +174,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             asm volatile("" : "+v"(pk));                        // opaque: unpack at the use
             const int h = pk >> 24, py = pk & 255;
             const int n = h ? c.n[NT - 1] : c.n[0], y0 = h ? c.y0[NT - 1] : c.y0[0], x0 = h ? c.x0[NT - 1] : c.x0[0];
-            const int iy = y0 + py;
+            const int iy = y0 + py + R0;
             int ix = x0 + ((pk >> 8) & 255), img = n;
             bool in = n >= 0 && py != 255 && (unsigned)iy < (unsigned)a.H;
             if (STRIP) {                                        // position p holds image A's column x0 + p up to its right padding (column W), behind it image B from column 0
                 const bool second = ix > a.W;
-                img += second ? 1 : 0; ix = second ? ix - a.W - 1 : ix;
+                img += second ? 1 : 0; ix = second ? ix - a.W - GW : ix;     // (positions W + 1 .. W + GW - 2 are never read; W + GW - 1 is image B's left padding)
                 in = in && img < a.n_img;
             }
             in = in && (unsigned)ix < (unsigned)a.W;
@@ -218,7 +229,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             const int tile = pair * NT + t;
             int n, ty, c0;
             decode_tile(tile < a.n_tiles ? tile : 0, n, ty, c0);
-            set_pbase(t, fr + (fr >= a.W - c0 ? 1 : 0));
+            set_pbase(t, fr + (fr >= a.W - c0 ? GW : 0));
         }
     };
 
@@ -248,7 +259,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
             }
         half8 pq[PD + 1][NT];
         auto load_p = [&](int q, int set) {                     // q = dx * PH + patch row
-            const int K = (q % PH) * PW + q / PH;               // lin = K + frow
+            const int K = (q % PH - R0) * PW + q / PH;          // lin = K + frow
 #pragma unroll
             for (int t = 0; t < NT; t++)
                 pq[set][t] = *(const half8 *)(smem + (pb[NPB > 1 ? t : 0][K & 1][(K >> 1) & 3] + (K * 64 + t * P_BYTES)));
@@ -256,12 +267,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv3x3_wr(const WRArgs a) {
 #pragma unroll
         for (int dx = 0; dx < 3; dx++) {
             if (dx != dx_) continue;
-            constexpr int NR = ONE_ROW ? TH : PH, R0 = ONE_ROW ? 1 : 0;     // patch rows read: R0 .. R0 + NR - 1
+            constexpr int NR = ONE_ROW ? TH : PH, RF = ONE_ROW ? 1 : 0;     // patch rows read: RF .. RF + NR - 1
 #pragma unroll
-            for (int j = 0; j < PD; j++) load_p(dx * PH + R0 + j, j % (PD + 1));
+            for (int j = 0; j < PD; j++) load_p(dx * PH + RF + j, j % (PD + 1));
 #pragma unroll
             for (int j = 0; j < NR; j++) {
-                const int r = R0 + j;
+                const int r = RF + j;
                 const int q = dx * PH + r;
                 if (j + PD < NR) load_p(q + PD, (j + PD) % (PD + 1));
                 row_hook(dx, r);
@@ -714,8 +725,8 @@ bool conv_wr_applicable(const ConvArgs &a) {
 
 template <int TH, int NT, int NW, int NCH, int NS = 2, int XF = 0>
 static int wr_launch_t(fid_ctx *ctx, WRArgs &a, int n_tiles) {
-    constexpr int PW = (XF & 1) ? 19 : 18;
-    constexpr int P_BYTES = (((TH + 2) * PW * 64 + 1023) / 1024) * 1024;
+    constexpr int PW = (XF & 1) ? 18 + WR_STRIP_GW : 18;
+    constexpr int P_BYTES = ((((XF & 3) == 3 && WR_STRIP_GW == 8 ? TH : TH + 2) * PW * 64 + 1023) / 1024) * 1024;
     constexpr int RS_BYTES = NCH > 0 ? ((TH * 16 * NW * 32 + 1023) / 1024) * 1024 : 0;      // resident variant: the residual tile
     a.ncls = a.bias ? ((a.flags & CF_BORDER) ? 9 : 1) : 0;
     a.tab_off = NS * NT * P_BYTES + 1024 + RS_BYTES;
