@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec); ~6.3 TB/s is what a streaming copy achieves
-PROFILE_DIRS = ("r04", "r03", "r02", "r01")
+PROFILE_DIRS = ("r05", "r04", "r03", "r02", "r01")
 # persisted kernel plan (per conv op and batch size: kernel family / tile / split-K), keyed by device name and layer-table hash: with it
 # every box runs the same kernels and fp32 summation orders (bit-identical heads / embeddings) and nothing is timed at start-up.
 # The tracked file is loaded READ-ONLY (FID_PLAN_RO): picks missing from it are tuned as before but never written back by a bench

@@ -9,11 +9,11 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes2 -o k -- python3 $R/bench.py --steps 60 --warmup 3 --cpu-frames 0 --no-roofline --repeats 1 --no-one-lane > $O/lanes2.log 2>&1
 echo "lanes2 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes1 -o k -- python3 $R/bench.py --steps 60 --warmup 3 --cpu-frames 0 --no-roofline --repeats 1 --streams 1 > $O/lanes1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes1 -o k -- python3 $R/bench.py --steps 60 --warmup 3 --cpu-frames 0 --no-roofline --repeats 1 --streams 1 --no-one-lane > $O/lanes1.log 2>&1
 echo "lanes1 done"
 for c in f:FETCH_SIZE w:WRITE_SIZE; do
   for n in 2 6; do
-    rocprofv3 --kernel-trace --pmc ${c#*:} --output-format csv -d $O/${c%%:*}$n -o p -- python3 $R/bench.py --steps $n --warmup 1 --cpu-frames 0 --no-roofline --repeats 1 --streams 1 > $O/${c%%:*}$n.log 2>&1
+    rocprofv3 --kernel-trace --pmc ${c#*:} --output-format csv -d $O/${c%%:*}$n -o p -- python3 $R/bench.py --steps $n --warmup 1 --cpu-frames 0 --no-roofline --repeats 1 --streams 1 --no-one-lane > $O/${c%%:*}$n.log 2>&1
     echo "pmc ${c#*:} $n done"
   done
 done
