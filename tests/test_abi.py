@@ -70,7 +70,7 @@ def test_integration_md_names_resolve():
         ok = hasattr(mods[mod], attr) or (mod == "app" and (hasattr(mods["app"].FaceAnalysis, attr) or f"self.{attr} =" in inspect.getsource(mods["app"].FaceAnalysis))) or (mod == "session" and hasattr(mods["session"].HipSession, attr))
         assert ok, f"INTEGRATION.md names {mod}.{attr}"
         seen += 1
-    owner = {"SCRFD": "models", "ArcFace": "models", "Communicator": "pipeline", "FacePipeline": "pipeline", "FaceAnalysis": "app",
+    owner = {"SCRFD": "models", "ArcFace": "models", "Communicator": "pipeline", "FacePipeline": "pipeline", "GroupedFacePipeline": "pipeline", "FaceAnalysis": "app",
              "HipSession": "session", "GateConfig": "app"}
     for cls, meth in set(re.findall(r"\b(" + "|".join(owner) + r")\.([a-z_][A-Za-z0-9_]*)", doc)):
         m = importlib.import_module(f"{pkg}.{owner[cls]}")
@@ -82,4 +82,6 @@ def test_integration_md_names_resolve():
     assert list(inspect.signature(Communicator.__init__).parameters)[1:] == ["ctx", "world", "rank", "exchange_id"]
     assert re.search(r"Communicator\(ctx, world_size, rank, exchange_id\)", doc) and "Communicator.unique_id" not in doc
     p = list(inspect.signature(run_step_distributed).parameters)
-    assert p[:9] == ["pipe", "frames_dev", "H", "W", "gallery", "thresh", "q_local", "q_all", "dist"] and {"idx_all", "score_all", "match_scope"} <= set(p)
+    assert p[:9] == ["pipe", "frames_dev", "H", "W", "gallery", "thresh", "q_local", "q_all", "dist"] and {"idx_all", "score_all", "match_scope", "flush"} <= set(p)
+    from scrfd_arcface_facerecognition_amd.pipeline import GroupedFacePipeline
+    assert "group" in inspect.signature(GroupedFacePipeline.__init__).parameters
