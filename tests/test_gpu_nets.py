@@ -265,25 +265,27 @@ def test_plan_file_makes_runs_bit_identical(ctx, monkeypatch, tmp_path):
     c.close()
 
 
-def test_arcface_r50_chunk500_vs_oracle(ctx):
-    """BASELINE configs[3] launches IResNet-50 on chunks of 500 crops: the batch-500 kernel plans (two-tile weights-in-registers convs,
-    implicit GEMM with the weights in registers on the 7x7 / stride-2 layers) against the fp32 oracle on 4 of the 500 crops, plus the
-    size-independent properties on all of them (duplicates give identical rows, every embedding finite)."""
+@pytest.mark.parametrize("n_crops", [500, 585])
+def test_arcface_r50_chunk500_vs_oracle(ctx, n_crops):
+    """BASELINE configs[3] launches IResNet-50 on chunks of 500 crops (round 5: or 585 = 512 STRIP tiles on the 14x14 stage): the large-batch kernel
+    plans (two-tile weights-in-registers convs also on STRIP tiles -- a duplicated crop sits at another lane position of another tile and must still
+    give a bit-identical row --, implicit GEMM with the weights in registers on the 7x7 / stride-2 layers) against the fp32 oracle on 4 of the
+    crops, plus the size-independent properties on all of them (duplicates give identical rows, every embedding finite)."""
     from scrfd_arcface_facerecognition_amd.engine import CompiledNet
     from oracle import align as oalign, nets as onets
     net = archs.iresnet50()
     P = archs.synth_params(net, 0)
     rng = np.random.default_rng(500)
-    crops = rng.integers(0, 256, (500, 112, 112, 3), dtype=np.uint8)
+    crops = rng.integers(0, 256, (n_crops, 112, 112, 3), dtype=np.uint8)
     crops[123] = crops[7]
-    cn = CompiledNet(ctx, net, P, max_batch=500)
+    cn = CompiledNet(ctx, net, P, max_batch=n_crops)
     cn.run(crops)
-    e = cn.read(net.outputs[0], 500).reshape(500, -1)
+    e = cn.read(net.outputs[0], n_crops).reshape(n_crops, -1)
     cn.run(crops)
-    assert np.array_equal(e, cn.read(net.outputs[0], 500).reshape(500, -1))          # deterministic
+    assert np.array_equal(e, cn.read(net.outputs[0], n_crops).reshape(n_crops, -1))          # deterministic
     cn.close()
     assert np.isfinite(e).all() and np.array_equal(e[123], e[7])
-    for i in (0, 7, 250, 499):
+    for i in (0, 7, 250, n_crops - 1):
         ref = onets.run_net(net, P, oalign.blob_from_images([crops[i]], net.in_scale, net.in_mean))[net.outputs[0]].reshape(-1)
         assert 1 - float(ref @ e[i] / np.linalg.norm(ref) / np.linalg.norm(e[i])) < 1e-3, i
         assert np.abs(ref / np.linalg.norm(ref) - e[i] / np.linalg.norm(e[i])).max() < 1e-3, i
