@@ -41,7 +41,8 @@ def build(hw, c1, c2, acts, res, pre_bn):
 
 
 # (FID_FORCE_GEN, FID_FORCE_NS) per family; conv3x3_wr: NS 1 / 2 = one / two tiles per item, 3 = resident weights, 4 = four-slot ring, 6 / 7 = K split over two wave groups (conv_ks.hip) with one / two items per workgroup
-FAMILIES = [(1, None), (3, None), (5, None), (7, None), (8, None), (9, 1), (9, 2), (9, 3), (9, 4), (9, 6), (9, 7), (11, None)]
+# round 5: 8 = conv_ks on STRIP tiles, 9 / 29 / 39 = conv3x3_wr on STRIP tiles (one tile x 64 couts / a pair x 128 / one tile x 128 on eight waves), 10 = resident weights on STRIP tiles
+FAMILIES = [(1, None), (3, None), (5, None), (7, None), (8, None), (9, 1), (9, 2), (9, 3), (9, 4), (9, 6), (9, 7), (9, 8), (9, 9), (9, 29), (9, 39), (9, 10), (11, None)]
 
 
 def took(plans, gen, ns):
@@ -50,7 +51,8 @@ def took(plans, gen, ns):
             return False
         if gen != 9 or ns is None:
             return True
-        return {1: p["ns"] not in (1, 4, 6) and p["bm"] // 256 == 1, 2: p["ns"] not in (1, 4, 6) and p["bm"] // 256 == 2, 3: p["ns"] == 1, 4: p["ns"] == 4, 6: p["ns"] == 6 and p["bm"] == 256, 7: p["ns"] == 6 and p["bm"] == 512}[ns]
+        return {1: p["ns"] == 0 and p["bm"] // 256 == 1, 2: p["ns"] == 0 and p["bm"] // 256 == 2, 3: p["ns"] == 1, 4: p["ns"] == 4, 6: p["ns"] == 6 and p["bm"] == 256, 7: p["ns"] == 6 and p["bm"] == 512,
+                8: p["ns"] == 7, 9: p["ns"] == 8 and (p["bm"], p["bn"]) == (256, 64), 29: p["ns"] == 8 and p["bm"] == 512, 39: p["ns"] == 8 and (p["bm"], p["bn"]) == (256, 128), 10: p["ns"] == 9}[ns]
     return [p["name"] for p in plans if hit(p)]
 
 
