@@ -309,6 +309,60 @@ class VectorGallery:
         return [[(self.id_of[int(j)], float(s)) for j, s in zip(I[r], S[r]) if j >= 0] for r in range(n)]
 
 
+    # ---- the product layer's duplicate logic on top of search ("duplicate check @0.95, merge @0.8") ---------------------------------
+    def is_duplicate(self, embedding, duplicate_threshold: float = 0.95) -> bool:
+        """the vector half of the reference's `is_duplicate_image` (smart_face_recognition.py:2632-2641; config.json
+        `duplicate_similarity_threshold`): does the nearest stored embedding reach the threshold?"""
+        return len(self) > 0 and len(self.search(np.asarray(embedding, np.float32).reshape(1, self.dim), k=1, score_threshold=duplicate_threshold)[0]) > 0
+
+    def similarity_rows(self, ids) -> np.ndarray:
+        """cosine similarity of the stored embeddings `ids` against EVERY row of the store, fp32 [len(ids), capacity] (free rows: 0), computed on the
+        device in one GEMM per 1 024 ids (fid_cosine_matrix with the store's own unit rows as queries)"""
+        gal = self._gal
+        base = _gallery_ptr(gal)
+        out = np.empty((len(ids), gal.G), np.float32)
+        rows = np.asarray([self.row_of[i] for i in ids], dtype=np.int64)
+        stage = self.ctx.empty((min(1024, max(1, len(ids))), self.dim), np.float16)
+        cm = self.ctx.empty((stage.shape[0], gal.Gp), np.float32)
+        unit = self.ctx.borrow(base, (gal.Gp, self.dim), np.float16).download()          # (host copy of the unit rows: the gather of arbitrary ids)
+        for c0 in range(0, len(ids), stage.shape[0]):
+            blk = rows[c0:c0 + stage.shape[0]]
+            q = np.zeros(stage.shape, np.float16)
+            q[:len(blk)] = unit[blk]
+            stage.upload(q)
+            check(self.ctx.lib.fid_cosine_matrix(self.ctx.handle, gal.handle, C.c_void_p(stage.ptr), len(blk), C.c_void_p(cm.ptr)))
+            out[c0:c0 + len(blk)] = cm.download()[:len(blk), :gal.G]
+        return out
+
+    def find_and_merge_duplicates(self, similarity_threshold: float = 0.8):
+        """The reference's `find_and_merge_duplicates` (smart_face_recognition.py:2726-2797; config.json `merge_duplicate_threshold`) on the vector
+        store: ids in ascending order; every id that is still stored absorbs all LARGER ids whose similarity reaches the threshold (their rows are
+        deleted, as merge_duplicate_persons does through delete_embedding).  The G x G similarities come from the device in one pass (deletions only
+        remove candidates, no embedding changes); the greedy pass over them is the reference's loop.  Returns [(kept id, deleted id, similarity)]."""
+        ids = sorted(self.row_of)
+        if len(ids) < 2:
+            return []
+        sims = self.similarity_rows(ids)
+        col = np.asarray([self.row_of[i] for i in ids])
+        alive = {i: True for i in ids}
+        merges = []
+        for a, p1 in enumerate(ids):
+            if not alive[p1]:
+                continue
+            s = sims[a, col]
+            for b in np.argsort(-s, kind="stable"):
+                if s[b] < similarity_threshold:
+                    break
+                p2 = ids[int(b)]
+                if p2 <= p1 or not alive[p2]:
+                    continue
+                alive[p2] = False
+                merges.append((p1, p2, float(s[b])))
+        if merges:
+            self.delete([m[1] for m in merges])
+        return merges
+
+
 def _gallery_ptr(gal: Gallery) -> int:
     p = C.c_void_p()
     check(gal.ctx.lib.fid_gallery_data(gal.handle, C.byref(p)))

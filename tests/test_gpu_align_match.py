@@ -178,6 +178,59 @@ def test_vector_gallery_topk_upsert_delete(ctx):
     assert all(h[0] != "p15" for h in vg.search(queries[2:3], k=8, score_threshold=0.0)[0])   # deleted id never returned
 
 
+def _duplicate_store(rng, n=120):
+    """person embeddings with planted duplicate structure: tight clusters (everyone within 0.8 of everyone), a CHAIN a ~ b ~ c whose ends are
+    below the threshold (the greedy order decides who absorbs whom), near-copies (>= 0.95) and unrelated persons"""
+    base = rng.standard_normal((n, 512)).astype(np.float32)
+
+    def near(v, cos):                                        # a vector at cosine `cos` from v
+        v = v / np.linalg.norm(v)
+        r = rng.standard_normal(512).astype(np.float32)
+        r -= (r @ v) * v
+        r /= np.linalg.norm(r)
+        return (cos * v + np.sqrt(1 - cos * cos) * r).astype(np.float32) * np.float32(rng.uniform(0.5, 2.0))
+    for i, j, c in ((40, 3, 0.93), (77, 3, 0.90), (78, 40, 0.97), (15, 90, 0.86), (91, 15, 0.99), (60, 61, 0.96)):
+        base[i] = near(base[j], c)
+    base[100] = near(base[50], 0.88)                         # chain: 50 ~ 100 ~ 101, 50 !~ 101
+    v50 = base[50] / np.linalg.norm(base[50])
+    v100 = base[100] / np.linalg.norm(base[100])
+    away = v100 - (v100 @ v50) * v50
+    away /= np.linalg.norm(away)
+    base[101] = (0.88 * v100 + np.sqrt(1 - 0.88 ** 2) * (0.9 * away + np.sqrt(1 - 0.81) * near(away, 0.0) / np.linalg.norm(near(away, 0.0)))).astype(np.float32)
+    return base
+
+
+def test_vector_gallery_duplicate_check_and_merge(ctx):
+    """SURVEY 8 f-3, the product layer's use of the store: `is_duplicate` (config.json duplicate_similarity_threshold 0.95) and
+    `find_and_merge_duplicates` (merge_duplicate_threshold 0.8) against the oracle's restatement of smart_face_recognition.py:2632-2641 / 2726-2797
+    (the Qdrant search itself is unpinned: no qdrant_client offline).  Pairs within 2e-3 of the threshold are kept out of the fixture by construction
+    and checked for; ids are inserted in a shuffled order so that store rows and id order differ."""
+    from scrfd_arcface_facerecognition_amd.engine import VectorGallery
+    rng = np.random.default_rng(55)
+    emb = _duplicate_store(rng)
+    ids = [int(i) for i in rng.permutation(1000)[:len(emb)]]
+    unit = emb / np.linalg.norm(emb, axis=1, keepdims=True)
+    S = unit @ unit.T
+    assert np.abs(np.abs(S[np.triu_indices(len(emb), 1)]) - 0.8).min() > 2e-3 and np.abs(S[np.triu_indices(len(emb), 1)] - 0.95).min() > 2e-3
+    vg = VectorGallery(ctx, 512, capacity=64)
+    order = rng.permutation(len(ids))
+    vg.upsert([ids[j] for j in order], emb[order])
+    # duplicate check of new embeddings: a near copy, a moderately similar one, an unrelated one
+    probes = np.stack([emb[7] * 3.0 + 0.01 * rng.standard_normal(512), emb[7] + 6.0 * rng.standard_normal(512), rng.standard_normal(512)]).astype(np.float32)
+    for p in probes:
+        assert vg.is_duplicate(p) == match.is_duplicate_embedding(p, ids, emb, 0.95)
+    assert vg.is_duplicate(probes[0]) and not vg.is_duplicate(probes[2])
+    want, survivors = match.find_and_merge_duplicates(ids, emb, 0.8)
+    got = vg.find_and_merge_duplicates(0.8)
+    assert len(want) >= 7 and [(a, b) for a, b, _ in got] == [(a, b) for a, b, _ in want]
+    assert max(abs(g[2] - w[2]) for g, w in zip(got, want)) < 1e-3
+    assert sorted(vg.row_of) == survivors and len(vg) == len(ids) - len(want)
+    assert vg.find_and_merge_duplicates(0.8) == []                    # idempotent: nothing left above the threshold
+    # the chain: the smaller id of (50's, 100's) absorbs the other; 101's person survives iff it was not within reach of the absorber
+    kept = {a for a, _, _ in want} | set(survivors)
+    assert all(b not in kept for _, b, _ in want)
+
+
 def test_zero_gallery_row_does_not_poison_the_match(ctx):
     """an all-zero target used to become a NaN fp16 row whose key outranked every real score and turned EVERY
     query into Unknown.  The reference skips such a target (`nan > x` is False, main.py:139-140) and matches the others."""

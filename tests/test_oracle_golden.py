@@ -225,3 +225,22 @@ def test_face_gates_match_the_reference():
     assert gates.select_best(side, kps)[:2] == (1, gates.SIDE_FACE)
     assert gates.select_best(dets, kps, dict(cfg, min_quality_threshold=0.99))[:2] == (1, gates.LOW_QUALITY)
     assert gates.select_best(dets, kps, cfg, poses=[(0, 0), (np.radians(50.0), 0), (0, 0)])[:2] == (1, gates.SIDE_FACE)
+
+
+def test_product_layer_duplicate_logic_restatement():
+    """oracle/match.py's restatement of the product layer's store logic (reference smart_face_recognition.py:2632-2641, 2726-2797,
+    qdrant_manager.py:137-183; Qdrant itself unpinned) on a hand-checkable store: ids 5 ~ 9 ~ 12 form a chain (5 !~ 12), 7 ~ 20 a pair."""
+    from oracle import match
+    e = np.zeros((5, 4), np.float32)
+    ids = [9, 5, 12, 20, 7]
+
+    def unit(a):
+        return np.array([np.cos(a), np.sin(a), 0, 0], np.float32)
+    e[1], e[0], e[2] = unit(0.0), unit(0.5), unit(1.0)               # cos(0.5) = 0.878 >= 0.8, cos(1.0) = 0.54 < 0.8
+    e[4], e[3] = np.array([0, 0, 1, 0], np.float32), np.array([0, 0, 0.99, 0.14], np.float32)
+    hits = match.search_similar(unit(0.1), ids, e, k=2, threshold=0.8)
+    assert [h[0] for h in hits] == [5, 9]
+    assert match.is_duplicate_embedding(unit(0.01), ids, e, 0.95) and not match.is_duplicate_embedding(unit(1.6), ids, e, 0.95)       # cos(0.6) = 0.825 to the nearest
+    merges, alive = match.find_and_merge_duplicates(ids, e, 0.8)
+    # 5 absorbs 9 (0.878); 12 was within reach of 9 only, and 9 is gone when 12's turn comes: it survives; 7 absorbs 20
+    assert [(a, b) for a, b, _ in merges] == [(5, 9), (7, 20)] and alive == [5, 7, 12]
