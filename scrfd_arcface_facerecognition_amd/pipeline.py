@@ -133,7 +133,7 @@ class GroupedFacePipeline(FacePipeline):
     Every step still detects, post-processes and aligns ITS batch of B frames at once (the frames may be overwritten as soon as
     `run_step` has been enqueued); the B*F crops of the group's steps collect in one buffer and the last step of the group sends all
     group*B*F of them through IResNet, the L2 normalisation and ONE gallery match.  IResNet-50 at 64 crops has one tile per CU on its
-    26 stage-3 layers (a launch = one latency chain); at 128 crops it runs at 810 instead of 664 TFLOP/s (gpurun_out/r05): the same
+    26 stage-3 layers (a launch = one latency chain); at 128 crops it runs at 810 instead of 664 TFLOP/s (profiles/r05/steady.txt): the same
     work per face, 18 % less time.  The price is latency: a step's identities exist when its group's last step has run
     (`flush` finishes a partial group).  Slots of step k of the group: [k*B*F, (k+1)*B*F) of `q`, `idx`, `score`."""
 
@@ -156,6 +156,8 @@ class GroupedFacePipeline(FacePipeline):
         if self.det.ctx is not self.ctx:
             raise ValueError("GroupedFacePipeline: detector and recogniser must share one context / stream")
         k, n = self.k, self.n_slots
+        if k >= self.group:
+            raise RuntimeError("GroupedFacePipeline.collect: the group is full -- embed_collected() / flush() it first")
         self.post = self.posts[k]
         self.detect(frames_dev, H, W)
         check(self.ctx.lib.fid_align_crops(self.ctx.handle, _lib._ptr(frames_dev), self.B, H, W,
