@@ -17,10 +17,11 @@
 // STRIP COLUMNS: on a 14-wide map eight images are seven exact fragments (a 14-column tile leaves lanes 14, 15 idle: 1.14 x the matrix work), on
 // 28 / 56 / 112 / 20 / 40-wide maps likewise.  A tile crosses at most one image boundary (host-checked): lanes behind it belong to the next image
 // and read GW patch positions further right: the right padding of image A and the left padding of image B sit between the two images in the
-// patch.  GW = 1 (one shared zero column, PW = 19) breaks the bank pattern of the fragment reads -- the 16 pixels of a fragment are no longer 16
-// CONSECUTIVE 64-byte positions, so one 256-byte bank row gets five of them: SQ_LDS_BANK_CONFLICT 47 % of the LDS cycles against 5 % (profiles/r05).
-// GW = 8 (PW = 26) moves the lanes behind the boundary by 512 bytes: the same bank row quarter and the same XOR swizzle as without the gap --
-// conflict-free again; used wherever the patch slots still fit (maps one tile high store only their TH real rows).
+// patch.  The default is GW = 1: ONE shared zero column (PW = 19).  It breaks the bank pattern of the fragment reads -- the 16 pixels of a fragment
+// are no longer 16 CONSECUTIVE 64-byte positions, so one 256-byte bank row gets five of them: SQ_LDS_BANK_CONFLICT 47 % of the LDS cycles against
+// 5 % (profiles/r05) -- and is still the faster form: GW = 8 (PW = 26; -DFID_STRIP_GW=8) moves the lanes behind the boundary by 512 bytes (the same
+// bank row quarter and XOR swizzle as without the gap: conflict-free again, maps one tile high then store only their TH real rows so that the
+// slots fit) and measured equal-to-slower (below: seven more cells per row in every LDS-DMA piece list).
 // Row-sharing, the tap order and every counted wait are unchanged; what changes is the
 // piece -> pixel mapping of the patch fetch, a per-item lane shift in the fragment addresses, and the lane -> pixel mapping of the epilogue.
 #include <type_traits>
